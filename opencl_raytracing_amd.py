@@ -1,0 +1,10 @@
+"""Import alias: the package directory is `opencl-raytracing_amd/` (hyphen)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("opencl-raytracing_amd")
+sys.modules[__name__] = _pkg

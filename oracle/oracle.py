@@ -1,0 +1,172 @@
+"""ctypes front-end of the parity checkers — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.
+
+  Oracle()     liboracle.so — the CPU restatement (pt_oracle.c), always available
+               after `make -C oracle` / __graft_entry__.build().
+  Reference()  _ref/libref.so — the unmodified reference kernel compiled for
+               x86-64 (build container only; absent on the GPU box unless the
+               prebuilt file travelled).
+Both take the product's host-side scene object (anything with .desc() and
+.texture_args(), i.e. opencl-raytracing_amd.scene.SceneCreator) so that oracle and
+GPU are fed byte-identical inputs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref.so")
+
+COUNTER_FIELDS = ("samples", "bounces", "t_sphere", "t_plane", "t_lens", "t_model", "t_mesh", "t_tri", "h_tri",
+                  "h_bounce", "n_scatter", "n_dielectric", "n_texfetch", "image_reads")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+def build(ref=True):
+    """make -C oracle (liboracle.so, and _ref/ when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all" if ref else os.path.join(HERE, "liboracle.so")])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Base:
+    def _scene_args(self, scene):
+        d = scene.desc()
+        tex, tw, th, layers = scene.texture_args()
+        self._keep = (d, scene)
+        return C.byref(d), tex, tw, th, layers
+
+
+class Oracle(_Base):
+    def __init__(self, path=ORACLE_SO):
+        if not os.path.isfile(path):
+            build(ref=False)
+        self.lib = C.CDLL(path)
+        self.lib.oracle_counters_bytes.restype = C.c_uint64
+
+    def make_random_table(self, seed):
+        out = np.empty(400000, dtype=np.float32)
+        rc = self.lib.oracle_make_random_table(C.c_uint64(seed), _fp(out), C.c_size_t(out.size))
+        assert rc == 0
+        return out
+
+    def render(self, scene, cam, table, w, h, mode, first=0, count=1, region=None, image=None, threads=1):
+        """mode 0: `trace`; 1: one `retrace` of sample `first` over `image`; 2: trace + count-1
+        retraces.  → (image h×w×4 float32 gamma space, Counters)."""
+        x0, y0, cw, ch = region if region else (0, 0, w, h)
+        img = np.zeros((h, w, 4), dtype=np.float32) if image is None else _f32(image).copy()
+        cn = Counters()
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        rc = self.lib.oracle_render(_fp(img), w, h, x0, y0, cw, ch, _fp(cam), _fp(table), sd, tex, tw, th, layers,
+                                    mode, C.c_uint32(first), C.c_uint32(count), threads, C.byref(cn))
+        assert rc == 0, "oracle_render failed"
+        return img, cn
+
+    def samples(self, scene, cam, table, w, h, xs, ys, ss):
+        xs, ys, ss = _u32(xs), _u32(ys), _u32(ss)
+        out = np.zeros((len(xs), 3), dtype=np.float32)
+        cn = Counters()
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        rc = self.lib.oracle_samples(w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers, _fp(xs), _fp(ys), _fp(ss),
+                                     C.c_size_t(len(xs)), _fp(out), C.byref(cn))
+        assert rc == 0
+        return out, cn
+
+    def linear_sum(self, scene, cam, table, w, h, region, first, count):
+        x0, y0, cw, ch = region
+        out = np.zeros((ch, cw, 3), dtype=np.float64)
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        rc = self.lib.oracle_linear_sum(_fp(out), w, h, x0, y0, cw, ch, _fp(cam), _fp(table), sd, tex, tw, th, layers,
+                                        C.c_uint32(first), C.c_uint32(count))
+        assert rc == 0
+        return out
+
+    def hit(self, kind, scene, rays, prim):
+        rays, prim = _f32(rays), _u32(prim)
+        out = np.zeros((len(prim), 12), dtype=np.float32)
+        sd = self._scene_args(scene)[0]
+        assert self.lib.oracle_hit(kind, sd, _fp(rays), _fp(prim), C.c_size_t(len(prim)), _fp(out)) == 0
+        return out
+
+    def hit_triangle(self, scene, rays, mesh, face):
+        rays, mesh, face = _f32(rays), _u32(mesh), _u32(face)
+        out = np.zeros((len(mesh), 12), dtype=np.float32)
+        sd = self._scene_args(scene)[0]
+        assert self.lib.oracle_hit_triangle(sd, _fp(rays), _fp(mesh), _fp(face), C.c_size_t(len(mesh)), _fp(out)) == 0
+        return out
+
+    def counters_bytes(self, cn):
+        return int(self.lib.oracle_counters_bytes(C.byref(cn)))
+
+
+class Reference(_Base):
+    """The compiled reference kernel (oracle/_ref/libref.so)."""
+
+    @staticmethod
+    def available():
+        return os.path.isfile(REF_SO)
+
+    def __init__(self, path=REF_SO):
+        self.lib = C.CDLL(path)
+
+    def trace(self, scene, cam, table, w, h, threads=1):
+        img = np.zeros((h, w, 4), dtype=np.float32)
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        assert self.lib.ref_trace(_fp(img), w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers, threads) == 0
+        return img
+
+    def retrace(self, image, scene, cam, table, w, h, sample, threads=1):
+        img = _f32(image).copy()
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        assert self.lib.ref_retrace(_fp(img), w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers,
+                                    C.c_uint32(sample), threads) == 0
+        return img
+
+    def samples(self, scene, cam, table, w, h, xs, ys, ss):
+        xs, ys, ss = _u32(xs), _u32(ys), _u32(ss)
+        out = np.zeros((len(xs), 3), dtype=np.float32)
+        sd, tex, tw, th, layers = self._scene_args(scene)
+        cam, table = _f32(cam), _f32(table)
+        assert self.lib.ref_samples(w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers, _fp(xs), _fp(ys), _fp(ss),
+                                    C.c_size_t(len(xs)), _fp(out)) == 0
+        return out
+
+    def hit(self, kind, scene, rays, prim):
+        rays, prim = _f32(rays), _u32(prim)
+        out = np.zeros((len(prim), 12), dtype=np.float32)
+        sd = self._scene_args(scene)[0]
+        assert self.lib.ref_hit(kind, sd, _fp(rays), _fp(prim), C.c_size_t(len(prim)), _fp(out)) == 0
+        return out
+
+    def hit_triangle(self, scene, rays, mesh, face):
+        rays, mesh, face = _f32(rays), _u32(mesh), _u32(face)
+        out = np.zeros((len(mesh), 12), dtype=np.float32)
+        sd = self._scene_args(scene)[0]
+        assert self.lib.ref_hit_triangle(sd, _fp(rays), _fp(mesh), _fp(face), C.c_size_t(len(mesh)), _fp(out)) == 0
+        return out
