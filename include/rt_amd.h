@@ -260,8 +260,9 @@ int rt_sample_counter(const rt_context *ctx, uint32_t *out);
  * Native fused path (new): samples first_sample .. first_sample+n-1 of every
  * owned pixel in ONE launch, each sample bit-identical to what `trace` /
  * `retrace` would have traced, summed per pixel in linear space in a fixed
- * order, added to the linear accumulator.  rt_clear() zeroes accumulator and
- * count; rt_resolve() writes image = sqrt(accumulator / count), alpha 1.
+ * order, added to the linear accumulator (RGB sum, and the sample count in the
+ * 4th channel, so accumulators of several ranks can simply be summed).
+ * rt_clear() zeroes it; rt_resolve() writes image = sqrt(sum / count), alpha 1.
  * 64 spp: rt_clear; rt_render_spp(cam, 0, 64); rt_resolve.
  */
 int rt_clear(rt_context *ctx);
@@ -295,10 +296,6 @@ int rt_read_linear(rt_context *ctx, float *rgba, size_t bytes);
  * (RCCL reduce of the radiance buffer, display interop). */
 int rt_device_image(rt_context *ctx, void **d_rgba);
 int rt_device_accum(rt_context *ctx, void **d_rgba);
-
-/* Tell the context how many samples its accumulator now holds (after an
- * external reduce over sample-range shards). */
-int rt_set_accum_count(rt_context *ctx, uint32_t count);
 
 /* ---- measurement --------------------------------------------------------- */
 

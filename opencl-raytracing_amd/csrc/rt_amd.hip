@@ -1,0 +1,802 @@
+// rt_amd.hip — kernels + C ABI of librt_amd.so (include/rt_amd.h), gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+// (see __graft_entry__.build()).  No CPU fallback exists: without a gfx950
+// device rt_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pt_device.hpp"
+
+using namespace pt;
+
+// =============================== device kernels ===============================
+
+enum RenderMode { MODE_ACCUM = 0, MODE_TRACE = 1, MODE_RETRACE = 2 };
+
+struct FrameParams {
+    float cam[12];
+    int w, h;
+    int tile_w_log2, tile_h_log2;
+    uint32_t tiles_x, tiles_total;
+    uint32_t rank, world;
+    uint32_t slot_begin, slot_end;  // owned pixel slots handled by this launch
+    uint32_t first, count;          // samples first .. first+count-1
+    uint32_t group_log2;            // lanes per pixel = 1 << group_log2 (<= 64)
+};
+
+// owned pixel slot → frame coordinates.  Slots enumerate this rank's tiles
+// (t = rank, rank+world, ...) tile after tile, row-major inside a tile.
+PT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, uint32_t &x, uint32_t &y) {
+    uint32_t tpix_log2 = fp.tile_w_log2 + fp.tile_h_log2;
+    uint32_t k = slot >> tpix_log2, in = slot & ((1u << tpix_log2) - 1u);
+    uint32_t t = fp.rank + k * fp.world;
+    if (t >= fp.tiles_total) return false;
+    uint32_t tx = t % fp.tiles_x, ty = t / fp.tiles_x;
+    x = (tx << fp.tile_w_log2) + (in & ((1u << fp.tile_w_log2) - 1u));
+    y = (ty << fp.tile_h_log2) + (in >> fp.tile_w_log2);
+    return x < (uint32_t)fp.w && y < (uint32_t)fp.h;
+}
+
+template <bool COUNT>
+PT_DEV void flush_counters(const LaneCounters &cn, unsigned long long *counters) {
+    if (!COUNT) return;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint32_t v = cn.c[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[i], (unsigned long long)v);
+    }
+}
+
+// One work-item per (pixel, sample lane).  Lane l of a group of g = 2^group_log2
+// lanes traces samples first+l, first+l+g, ... of its pixel and sums them in
+// that order; the g partial sums are combined by an xor butterfly (a fixed
+// tree), and the group's lane 0 updates the pixel:
+//   MODE_ACCUM   accum += (sum, count)                      (rt_render_spp)
+//   MODE_TRACE   image = sqrt(radiance(sample first))        (`trace`,  raytracer.cl:496-510)
+//   MODE_RETRACE image = sqrt(mix(new, image², k/(k+1)))     (`retrace`, raytracer.cl:512-532)
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp, float4 *__restrict__ accum,
+                                                 float4 *__restrict__ image, unsigned long long *counters) {
+    uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t g = 1u << fp.group_log2;
+    uint32_t slot = fp.slot_begin + (tid >> fp.group_log2);
+    uint32_t lane = tid & (g - 1u);
+    uint32_t x = 0, y = 0;
+    bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
+
+    LaneCounters cn;
+    if (COUNT)
+        for (int i = 0; i < 14; i++) cn.c[i] = 0;
+
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    if (valid) {
+        Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
+        for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
+            if (COUNT) cn.c[CN_SAMPLES]++;
+            V3 c = radiance<COUNT>(sc, r0, s, x, y, &cn);
+            sum = sum + c;
+        }
+    }
+    for (uint32_t off = g >> 1; off > 0; off >>= 1) {
+        sum.x += __shfl_xor(sum.x, off);
+        sum.y += __shfl_xor(sum.y, off);
+        sum.z += __shfl_xor(sum.z, off);
+    }
+    if (valid && lane == 0) {
+        size_t pix = (size_t)y * fp.w + x;
+        if (MODE == MODE_ACCUM) {
+            float4 a = accum[pix];
+            a.x += sum.x;
+            a.y += sum.y;
+            a.z += sum.z;
+            a.w += (float)fp.count;
+            accum[pix] = a;
+        } else if (MODE == MODE_TRACE) {
+            image[pix] = make_float4(sqrtf(sum.x), sqrtf(sum.y), sqrtf(sum.z), 1.0f);
+        } else {
+            if (COUNT) cn.c[CN_IMAGE_READS]++;
+            float4 prev = image[pix];
+            V3 lin = mk(prev.x * prev.x, prev.y * prev.y, prev.z * prev.z);
+            float k = (float)fp.first / (float)(fp.first + 1u);
+            V3 o = mk(sum.x + (lin.x - sum.x) * k, sum.y + (lin.y - sum.y) * k, sum.z + (lin.z - sum.z) * k);
+            image[pix] = make_float4(sqrtf(o.x), sqrtf(o.y), sqrtf(o.z), 1.0f);
+        }
+    }
+    flush_counters<COUNT>(cn, counters);
+}
+
+// parity probe: one work-item per listed pixel-sample
+__global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
+                                                const uint32_t *__restrict__ ys, const uint32_t *__restrict__ ss,
+                                                uint32_t n, float *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
+    V3 c = radiance<false>(sc, r0, ss[i], xs[i], ys[i], nullptr);
+    out[3 * i] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
+}
+
+// image = sqrt(accum / count), alpha 1; pixels this rank does not own stay 0
+__global__ __launch_bounds__(256) void pt_resolve(const float4 *__restrict__ accum, float4 *__restrict__ image,
+                                                  uint32_t n, float count, int linear_only) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i];
+    float cnt = count > 0.0f ? count : a.w;
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (cnt > 0.0f) {
+        float rx = a.x / cnt, ry = a.y / cnt, rz = a.z / cnt;
+        o = linear_only ? make_float4(rx, ry, rz, 1.0f) : make_float4(sqrtf(rx), sqrtf(ry), sqrtf(rz), 1.0f);
+    }
+    image[i] = o;
+}
+
+// ================================== host side ==================================
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_create_error;
+
+// Philox-4x32-10 random table — see rt_set_seed in rt_amd.h, DESIGN.md "random table"
+void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int round = 0; round < 10; round++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+inline float u24(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+void make_table(uint64_t seed, float *out) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (uint32_t i = 0; i < RT_RANDOM_BUFFER_SIZE; i++) {
+        uint32_t w[4];
+        philox4x32_10(i, 0, 0, 0, k0, k1, w);
+        out[3 * RT_RANDOM_BUFFER_SIZE + i] = u24(w[3]);
+        for (uint32_t attempt = 0;; attempt++) {
+            if (attempt) philox4x32_10(i, attempt, 0, 0, k0, k1, w);
+            // volatile: keep each product/sum a separately rounded binary32 operation on the host
+            volatile float x = 2.0f * u24(w[0]) - 1.0f, y = 2.0f * u24(w[1]) - 1.0f, z = 2.0f * u24(w[2]) - 1.0f;
+            volatile float xx = x * x, yy = y * y, zz = z * z;
+            volatile float s2 = xx + yy;
+            volatile float s3 = s2 + zz;
+            if (s3 < 1.0f) {
+                out[3 * i] = x;
+                out[3 * i + 1] = y;
+                out[3 * i + 2] = z;
+                break;
+            }
+        }
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t upload(const T *src, size_t count) {
+        release();
+        size_t alloc = count ? count : 1;  // empty arrays become 1-element dummies (src/scene.cpp:41-44)
+        hipError_t e = hipMalloc((void **)&p, alloc * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = count;
+        if (count) e = hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+        else e = hipMemset(p, 0, sizeof(T));
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string error;
+    std::string dev_name, dev_arch;
+    int cu_count = 0;
+
+    DevBuf<rt_material> materials;
+    DevBuf<rt_sphere> spheres;
+    DevBuf<rt_plane> planes;
+    DevBuf<rt_lens> lenses;
+    DevBuf<rt_float3> vertices;
+    DevBuf<rt_float2> uvs;
+    DevBuf<uint32_t> indices;
+    DevBuf<rt_mesh> meshes;
+    DevBuf<rt_model> models;
+    DevBuf<float> table;
+    DevBuf<float4> tex;
+    int tex_w = 1, tex_h = 1, tex_layers = 0;
+    bool have_scene = false;
+    bool scene_uses_textures = false;
+    uint32_t max_texture_id = 0;
+
+    float4 *d_image = nullptr;
+    float4 *d_accum = nullptr;
+    unsigned long long *d_counters = nullptr;
+    uint32_t accum_count = 0;
+    uint32_t sample_counter = 0;
+    bool count_enabled = false;
+
+    int rank = 0, world = 1, tile_w_log2 = 3, tile_h_log2 = 3;
+    uint32_t max_threads_per_launch = 1u << 30;
+};
+
+namespace {
+
+int fail(rt_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else {
+        std::lock_guard<std::mutex> lk(g_err_mutex);
+        g_create_error = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, RT_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int alloc_frame(rt_context *ctx, int w, int h) {
+    if (ctx->d_image) (void)hipFree(ctx->d_image);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    ctx->d_image = ctx->d_accum = nullptr;
+    size_t bytes = (size_t)w * h * sizeof(float4);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_image, bytes));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_accum, bytes));
+    HIP_TRY(ctx, hipMemset(ctx->d_image, 0, bytes));
+    HIP_TRY(ctx, hipMemset(ctx->d_accum, 0, bytes));
+    ctx->width = w;
+    ctx->height = h;
+    ctx->accum_count = 0;
+    ctx->sample_counter = 0;
+    return RT_OK;
+}
+
+DeviceScene device_scene(const rt_context *ctx) {
+    DeviceScene s;
+    s.materials = ctx->materials.p;
+    s.spheres = ctx->spheres.p;
+    s.planes = ctx->planes.p;
+    s.lenses = ctx->lenses.p;
+    s.vertices = ctx->vertices.p;
+    s.uvs = ctx->uvs.p;
+    s.indices = ctx->indices.p;
+    s.meshes = ctx->meshes.p;
+    s.models = ctx->models.p;
+    s.table = ctx->table.p;
+    s.tex = ctx->tex.p;
+    s.tex_w = ctx->tex_w;
+    s.tex_h = ctx->tex_h;
+    s.tex_layers = ctx->tex_layers;
+    s.sphere_count = (uint32_t)ctx->spheres.n;
+    s.plane_count = (uint32_t)ctx->planes.n;
+    s.lens_count = (uint32_t)ctx->lenses.n;
+    s.model_count = (uint32_t)ctx->models.n;
+    return s;
+}
+
+struct Shard {
+    uint32_t tiles_x, tiles_total, owned_tiles, slots;
+};
+Shard shard_of(const rt_context *ctx) {
+    Shard s;
+    uint32_t tw = 1u << ctx->tile_w_log2, th = 1u << ctx->tile_h_log2;
+    s.tiles_x = (ctx->width + tw - 1) / tw;
+    uint32_t tiles_y = (ctx->height + th - 1) / th;
+    s.tiles_total = s.tiles_x * tiles_y;
+    s.owned_tiles = s.tiles_total > (uint32_t)ctx->rank ? (s.tiles_total - ctx->rank + ctx->world - 1) / ctx->world : 0;
+    s.slots = s.owned_tiles * tw * th;
+    return s;
+}
+
+FrameParams frame_params(const rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2) {
+    FrameParams fp;
+    memcpy(fp.cam, cam, sizeof fp.cam);
+    Shard sh = shard_of(ctx);
+    fp.w = ctx->width;
+    fp.h = ctx->height;
+    fp.tile_w_log2 = ctx->tile_w_log2;
+    fp.tile_h_log2 = ctx->tile_h_log2;
+    fp.tiles_x = sh.tiles_x;
+    fp.tiles_total = sh.tiles_total;
+    fp.rank = ctx->rank;
+    fp.world = ctx->world;
+    fp.slot_begin = 0;
+    fp.slot_end = sh.slots;
+    fp.first = first;
+    fp.count = count;
+    fp.group_log2 = glog2;
+    return fp;
+}
+
+int check_ready(rt_context *ctx, const float *cam) {
+    if (!ctx) return RT_EINVAL;
+    if (!cam) return fail(ctx, RT_EINVAL, "camera block is NULL");
+    if (!ctx->have_scene) return fail(ctx, RT_ESTATE, "no scene: call rt_set_scene first");
+    if (ctx->scene_uses_textures && (ctx->tex_layers <= 0 || ctx->max_texture_id >= (uint32_t)ctx->tex_layers))
+        return fail(ctx, RT_ERANGE, "scene has textured meshes (max texture id %u) but only %d texture layers are set",
+                    ctx->max_texture_id, ctx->tex_layers);
+    return RT_OK;
+}
+
+template <int MODE>
+int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2) {
+    FrameParams fp = frame_params(ctx, cam, first, count, glog2);
+    DeviceScene sc = device_scene(ctx);
+    uint32_t slots = fp.slot_end;
+    if (slots == 0) return RT_OK;
+    // split very long launches into slot ranges (keeps single kernels short on huge scenes)
+    uint32_t slots_per_launch = ctx->max_threads_per_launch >> glog2;
+    if (slots_per_launch == 0) slots_per_launch = 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (uint32_t b = 0; b < slots; b += slots_per_launch) {
+        fp.slot_begin = b;
+        fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
+        uint64_t threads = (uint64_t)(fp.slot_end - fp.slot_begin) << glog2;
+        dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+        if (ctx->count_enabled)
+            hipLaunchKernelGGL((pt_render<MODE, true>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum, ctx->d_image,
+                               ctx->d_counters);
+        else
+            hipLaunchKernelGGL((pt_render<MODE, false>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum,
+                               ctx->d_image, ctx->d_counters);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+uint32_t group_log2_for(uint32_t count) {
+    uint32_t g = 0;
+    while ((1u << g) < count && g < 6) g++;
+    return g;
+}
+
+}  // namespace
+
+// ================================== C ABI =====================================
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_last_error(const rt_context *ctx) {
+    if (ctx) return ctx->error.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    return g_create_error.c_str();
+}
+
+int rt_make_random_table(uint64_t seed, float *out, size_t n) {
+    if (!out || n != RT_RANDOM_TABLE_FLOATS) return fail(nullptr, RT_EINVAL, "table must hold %d floats", RT_RANDOM_TABLE_FLOATS);
+    make_table(seed, out);
+    return RT_OK;
+}
+
+int rt_create(int device, int width, int height, rt_context **out) {
+    if (!out) return fail(nullptr, RT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (width < 1 || height < 1 || width > RT_MAX_DIM || height > RT_MAX_DIM)
+        return fail(nullptr, RT_EINVAL, "frame size %dx%d outside 1..%d", width, height, RT_MAX_DIM);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(nullptr, RT_ENODEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(nullptr, RT_ENODEVICE, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, RT_EHIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RT_ENODEVICE, "device %d is %s; librt_amd.so carries gfx950 code only", device,
+                    prop.gcnArchName);
+    rt_context *ctx = new (std::nothrow) rt_context();
+    if (!ctx) return fail(nullptr, RT_EHIP, "out of host memory");
+    ctx->device = device;
+    ctx->dev_name = prop.name;
+    ctx->dev_arch = prop.gcnArchName;
+    ctx->cu_count = prop.multiProcessorCount;
+    int rc = RT_OK;
+    auto bail = [&](int code) {
+        {
+            std::lock_guard<std::mutex> lk(g_err_mutex);
+            g_create_error = ctx->error;
+        }
+        rt_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) { ctx->error = "hipSetDevice failed"; return bail(RT_EHIP); }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->error = "hipStreamCreate failed"; return bail(RT_EHIP); }
+    ctx->stream = ctx->own_stream;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
+    if (hipMalloc((void **)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
+    if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
+    if ((rc = rt_set_seed(ctx, 0xC0FFEEull)) != RT_OK) return bail(rc);
+    if ((rc = rt_set_textures(ctx, nullptr, 0, 0, 0)) != RT_OK) return bail(rc);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    ctx->materials.release(); ctx->spheres.release(); ctx->planes.release(); ctx->lenses.release();
+    ctx->vertices.release(); ctx->uvs.release(); ctx->indices.release(); ctx->meshes.release(); ctx->models.release();
+    ctx->table.release(); ctx->tex.release();
+    if (ctx->d_image) (void)hipFree(ctx->d_image);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int rt_resize(rt_context *ctx, int width, int height) {
+    if (!ctx) return RT_EINVAL;
+    if (width < 1 || height < 1 || width > RT_MAX_DIM || height > RT_MAX_DIM)
+        return fail(ctx, RT_EINVAL, "frame size %dx%d outside 1..%d", width, height, RT_MAX_DIM);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return alloc_frame(ctx, width, height);
+}
+
+int rt_set_stream(rt_context *ctx, void *hip_stream) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->timed = false;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
+    if (!ctx) return RT_EINVAL;
+    if (!d) return fail(ctx, RT_EINVAL, "scene is NULL");
+    struct { const void *p; uint32_t n; const char *name; } arrs[] = {
+        {d->materials, d->material_count, "materials"}, {d->spheres, d->sphere_count, "spheres"},
+        {d->planes, d->plane_count, "planes"}, {d->lenses, d->lens_count, "lenses"},
+        {d->vertices, d->vertex_count, "vertices"}, {d->uvs, d->uv_count, "uvs"},
+        {d->indices, d->index_count, "indices"}, {d->meshes, d->mesh_count, "meshes"},
+        {d->models, d->model_count, "models"}};
+    for (auto &a : arrs)
+        if (a.n && !a.p) return fail(ctx, RT_EINVAL, "%s: count %u but NULL pointer", a.name, a.n);
+    if (d->uv_count != 0 && d->uv_count != d->vertex_count)
+        return fail(ctx, RT_EINVAL, "uv_count (%u) must be 0 or vertex_count (%u)", d->uv_count, d->vertex_count);
+    // validate every index the kernels dereference
+    for (uint32_t i = 0; i < d->material_count; i++)
+        if (d->materials[i].type < 0 || d->materials[i].type > RT_LIGHT)
+            return fail(ctx, RT_EINVAL, "material %u has unknown type %d", i, d->materials[i].type);
+    for (uint32_t i = 0; i < d->sphere_count; i++)
+        if (d->spheres[i].mat_ID >= d->material_count) return fail(ctx, RT_ERANGE, "sphere %u: material %u does not exist", i, d->spheres[i].mat_ID);
+    for (uint32_t i = 0; i < d->plane_count; i++)
+        if (d->planes[i].mat_ID >= d->material_count) return fail(ctx, RT_ERANGE, "plane %u: material %u does not exist", i, d->planes[i].mat_ID);
+    for (uint32_t i = 0; i < d->lens_count; i++)
+        if (d->lenses[i].mat_ID >= d->material_count) return fail(ctx, RT_ERANGE, "lens %u: material %u does not exist", i, d->lenses[i].mat_ID);
+    bool uses_tex = false;
+    uint32_t max_tex = 0;
+    for (uint32_t i = 0; i < d->model_count; i++) {
+        const rt_model &mo = d->models[i];
+        if (mo.mat_ID >= d->material_count) return fail(ctx, RT_ERANGE, "model %u: material %u does not exist", i, mo.mat_ID);
+        if ((uint64_t)mo.mesh_anchor + mo.mesh_count > d->mesh_count) return fail(ctx, RT_ERANGE, "model %u: meshes [%u,+%u) outside the mesh array (%u)", i, mo.mesh_anchor, mo.mesh_count, d->mesh_count);
+        bool textured = d->materials[mo.mat_ID].type == RT_TEXTURED;
+        for (uint32_t k = 0; k < mo.mesh_count; k++) {
+            const rt_mesh &me = d->meshes[mo.mesh_anchor + k];
+            if (textured) {
+                uses_tex = true;
+                if (me.texture_ID > max_tex) max_tex = me.texture_ID;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < d->mesh_count; i++) {
+        const rt_mesh &me = d->meshes[i];
+        if ((uint64_t)me.index_anchor + 3ull * me.face_count > d->index_count)
+            return fail(ctx, RT_ERANGE, "mesh %u: indices [%u,+3*%u) outside the index array (%u)", i, me.index_anchor, me.face_count, d->index_count);
+        for (uint64_t k = 0; k < 3ull * me.face_count; k++)
+            if ((uint64_t)me.vertex_anchor + d->indices[me.index_anchor + k] >= d->vertex_count)
+                return fail(ctx, RT_ERANGE, "mesh %u: vertex index %u (+anchor %u) outside the vertex array (%u)", i, d->indices[me.index_anchor + k], me.vertex_anchor, d->vertex_count);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false;
+    HIP_TRY(ctx, ctx->materials.upload(d->materials, d->material_count));
+    HIP_TRY(ctx, ctx->spheres.upload(d->spheres, d->sphere_count));
+    HIP_TRY(ctx, ctx->planes.upload(d->planes, d->plane_count));
+    HIP_TRY(ctx, ctx->lenses.upload(d->lenses, d->lens_count));
+    HIP_TRY(ctx, ctx->vertices.upload(d->vertices, d->vertex_count));
+    if (d->uv_count) HIP_TRY(ctx, ctx->uvs.upload(d->uvs, d->uv_count));
+    else {
+        std::vector<rt_float2> zeros(d->vertex_count ? d->vertex_count : 1, rt_float2{0.0f, 0.0f});
+        HIP_TRY(ctx, ctx->uvs.upload(zeros.data(), d->vertex_count));
+    }
+    HIP_TRY(ctx, ctx->indices.upload(d->indices, d->index_count));
+    HIP_TRY(ctx, ctx->meshes.upload(d->meshes, d->mesh_count));
+    HIP_TRY(ctx, ctx->models.upload(d->models, d->model_count));
+    ctx->scene_uses_textures = uses_tex;
+    ctx->max_texture_id = max_tex;
+    ctx->have_scene = true;
+    ctx->sample_counter = 0;
+    return RT_OK;
+}
+
+int rt_set_textures(rt_context *ctx, const float *rgba, int w, int h, int layers) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (layers == 0) {
+        float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        HIP_TRY(ctx, ctx->tex.upload(&zero, 1));
+        ctx->tex_w = ctx->tex_h = 1;
+        ctx->tex_layers = 0;
+        return RT_OK;
+    }
+    if (!rgba || w < 1 || h < 1 || layers < 1 || w > 32768 || h > 32768 || layers > 2048)
+        return fail(ctx, RT_EINVAL, "bad texture array %dx%dx%d", w, h, layers);
+    HIP_TRY(ctx, ctx->tex.upload((const float4 *)rgba, (size_t)w * h * layers));
+    ctx->tex_w = w;
+    ctx->tex_h = h;
+    ctx->tex_layers = layers;
+    return RT_OK;
+}
+
+int rt_set_random_table(rt_context *ctx, const float *table, size_t n) {
+    if (!ctx) return RT_EINVAL;
+    if (!table || n != RT_RANDOM_TABLE_FLOATS) return fail(ctx, RT_EINVAL, "table must hold %d floats", RT_RANDOM_TABLE_FLOATS);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // 2 floats of slack: getVec reads idx..idx+2 with idx < 100000 — inside the table already
+    HIP_TRY(ctx, ctx->table.upload(table, n));
+    return RT_OK;
+}
+
+int rt_set_seed(rt_context *ctx, uint64_t seed) {
+    if (!ctx) return RT_EINVAL;
+    std::vector<float> t(RT_RANDOM_TABLE_FLOATS);
+    make_table(seed, t.data());
+    return rt_set_random_table(ctx, t.data(), t.size());
+}
+
+int rt_get_random_table(rt_context *ctx, float *out, size_t n) {
+    if (!ctx) return RT_EINVAL;
+    if (!out || n != RT_RANDOM_TABLE_FLOATS) return fail(ctx, RT_EINVAL, "table must hold %d floats", RT_RANDOM_TABLE_FLOATS);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->table.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_set_shard(rt_context *ctx, int rank, int world, int tile_w, int tile_h) {
+    if (!ctx) return RT_EINVAL;
+    auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) l++; return (1 << l) == v ? l : -1; };
+    int lw = log2_exact(tile_w), lh = log2_exact(tile_h);
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, RT_EINVAL, "rank %d of %d", rank, world);
+    if (tile_w < 1 || tile_h < 1 || lw < 0 || lh < 0 || lw + lh > 16)
+        return fail(ctx, RT_EINVAL, "tile %dx%d: sides must be powers of two, area <= 65536", tile_w, tile_h);
+    ctx->rank = rank;
+    ctx->world = world;
+    ctx->tile_w_log2 = lw;
+    ctx->tile_h_log2 = lh;
+    return RT_OK;
+}
+
+int rt_render(rt_context *ctx, const float camera[12]) {
+    int rc = check_ready(ctx, camera);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->sample_counter = 0;  // src/raytracer.cpp:128
+    if ((rc = launch_render<MODE_TRACE>(ctx, camera, 0, 1, 0)) != RT_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // queue.finish(), src/raytracer.cpp:140
+    return RT_OK;
+}
+
+int rt_render_again(rt_context *ctx, const float camera[12]) {
+    int rc = check_ready(ctx, camera);
+    if (rc) return rc;
+    if (ctx->sample_counter >= RT_MAX_SAMPLE) return fail(ctx, RT_EINVAL, "sample counter limit %u reached", RT_MAX_SAMPLE);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->sample_counter++;  // src/raytracer.cpp:147
+    if ((rc = launch_render<MODE_RETRACE>(ctx, camera, ctx->sample_counter, 1, 0)) != RT_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_sample_counter(const rt_context *ctx, uint32_t *out) {
+    if (!ctx || !out) return RT_EINVAL;
+    *out = ctx->sample_counter;
+    return RT_OK;
+}
+
+int rt_clear(rt_context *ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
+    ctx->accum_count = 0;
+    return RT_OK;
+}
+
+int rt_render_spp(rt_context *ctx, const float camera[12], uint32_t first_sample, uint32_t n_samples) {
+    int rc = check_ready(ctx, camera);
+    if (rc) return rc;
+    if (n_samples == 0) return RT_OK;
+    if ((uint64_t)first_sample + n_samples - 1 > RT_MAX_SAMPLE)
+        return fail(ctx, RT_EINVAL, "samples %u..+%u exceed the limit %u", first_sample, n_samples, RT_MAX_SAMPLE);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = launch_render<MODE_ACCUM>(ctx, camera, first_sample, n_samples, group_log2_for(n_samples))) != RT_OK) return rc;
+    ctx->accum_count += n_samples;
+    return RT_OK;
+}
+
+static int resolve_into(rt_context *ctx, int linear_only) {
+    uint32_t n = (uint32_t)ctx->width * ctx->height;
+    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_image, n, 0.0f,
+                       linear_only);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve(rt_context *ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return resolve_into(ctx, 0);
+}
+
+int rt_sync(rt_context *ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_samples(rt_context *ctx, const float camera[12], const uint32_t *x, const uint32_t *y,
+                     const uint32_t *sample, size_t n, float *out_rgb) {
+    int rc = check_ready(ctx, camera);
+    if (rc) return rc;
+    if (n == 0) return RT_OK;
+    if (!x || !y || !sample || !out_rgb || n > (1u << 28)) return fail(ctx, RT_EINVAL, "bad probe arrays");
+    for (size_t i = 0; i < n; i++)
+        if (x[i] >= (uint32_t)ctx->width || y[i] >= (uint32_t)ctx->height || sample[i] > RT_MAX_SAMPLE)
+            return fail(ctx, RT_EINVAL, "probe %zu (%u,%u,%u) outside the frame / sample range", i, x[i], y[i], sample[i]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_in = nullptr;
+    float *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_in, 3 * n * sizeof(uint32_t)));
+    if (hipMalloc((void **)&d_out, 3 * n * sizeof(float)) != hipSuccess) { (void)hipFree(d_in); return fail(ctx, RT_EHIP, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(d_in, x, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in + n, y, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in + 2 * n, sample, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        FrameParams fp = frame_params(ctx, camera, 0, 1, 0);
+        hipLaunchKernelGGL(pt_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, device_scene(ctx), fp,
+                           d_in, d_in + n, d_in + 2 * n, (uint32_t)n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, d_out, 3 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RT_EHIP, "probe: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_read_image(rt_context *ctx, float *rgba, size_t bytes) {
+    if (!ctx) return RT_EINVAL;
+    size_t need = (size_t)ctx->width * ctx->height * sizeof(float4);
+    if (!rgba || bytes != need) return fail(ctx, RT_EINVAL, "image buffer must be %zu bytes", need);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->d_image, need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_read_linear(rt_context *ctx, float *rgba, size_t bytes) {
+    if (!ctx) return RT_EINVAL;
+    size_t need = (size_t)ctx->width * ctx->height * sizeof(float4);
+    if (!rgba || bytes != need) return fail(ctx, RT_EINVAL, "image buffer must be %zu bytes", need);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float4 *tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&tmp, need));
+    uint32_t n = (uint32_t)ctx->width * ctx->height;
+    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, tmp, n, 0.0f, 1);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgba, tmp, need, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, RT_EHIP, "read_linear: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_device_image(rt_context *ctx, void **d_rgba) {
+    if (!ctx || !d_rgba) return RT_EINVAL;
+    *d_rgba = ctx->d_image;
+    return RT_OK;
+}
+
+int rt_device_accum(rt_context *ctx, void **d_rgba) {
+    if (!ctx || !d_rgba) return RT_EINVAL;
+    *d_rgba = ctx->d_accum;
+    return RT_OK;
+}
+
+int rt_enable_counters(rt_context *ctx, int enable) {
+    if (!ctx) return RT_EINVAL;
+    ctx->count_enabled = enable != 0;
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_context *ctx) {
+    if (!ctx) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    return RT_OK;
+}
+
+int rt_get_counters(rt_context *ctx, rt_counters *out) {
+    if (!ctx || !out) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[16];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t *o = (uint64_t *)out;
+    for (int i = 0; i < 14; i++) o[i] = h[i];
+    return RT_OK;
+}
+
+uint64_t rt_counters_bytes(const rt_counters *c) {
+    if (!c) return 0;
+    return 32 * c->t_sphere + 48 * c->t_plane + 64 * c->t_lens + 12 * c->t_model + 16 * c->t_mesh + 60 * c->t_tri +
+           36 * c->h_tri + 48 * c->h_bounce + 12 * c->n_scatter + 4 * c->n_dielectric + 64 * c->n_texfetch +
+           (48 + 16) * c->samples + 16 * c->image_reads;
+}
+
+int rt_last_kernel_ms(rt_context *ctx, float *ms) {
+    if (!ctx || !ms) return RT_EINVAL;
+    if (!ctx->timed) return fail(ctx, RT_ESTATE, "no render call has been timed yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RT_OK;
+}
+
+int rt_device_info(rt_context *ctx, char *name, size_t name_len, int *cu_count, char *arch, size_t arch_len) {
+    if (!ctx) return RT_EINVAL;
+    if (name && name_len) snprintf(name, name_len, "%s", ctx->dev_name.c_str());
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", ctx->dev_arch.c_str());
+    if (cu_count) *cu_count = ctx->cu_count;
+    return RT_OK;
+}
+
+}  // extern "C"
