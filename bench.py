@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path tracer.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
+
+Metric (BASELINE.json): Msamples/s at 1920×1080, 64 spp, and the fraction of the
+HBM roofline.  One *step* = one pass of the hot path over one frame: clear,
+ONE fused launch tracing every pixel-sample of the frame (samples 0..spp-1 of
+every pixel), resolve to the gamma image, and — for N > 1 — the RCCL reduce of
+the tile-sharded radiance buffer to rank 0.  Scene, camera block and random
+table are resident in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the 1920×1080 frame
+is cut into 8×8 tiles interleaved over ranks; per-GPU work is held fixed (weak
+scaling) by giving every pixel 64·N samples, so each rank traces 132.7 M
+pixel-samples per step exactly as at N = 1.  value = pixel-samples all ranks traced
+÷ max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: "roofline" (algorithmic bytes of the reference kernel per launch ÷ the
+kernel's HIP-event duration, against the 8 TB/s HBM peak) and "cpu_baseline" (the
+oracle / compiled reference kernel timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOAD_DESC = {
+    "c2": "C2 Cornell-style: 8 spheres + 1 plane, 1920x1080, 64 spp",
+    "c3": "C3 textured 12-triangle cube + 4 spheres, 1920x1080, 256 spp",
+    "c4": "C4 100k random spheres + plane, 1920x1080, 64 spp",
+    "c5": "C5 50k-triangle dielectric mesh, 3840x2160, 512 spp",
+}
+
+
+def cpu_baseline(wl, table, budget_s=20.0):
+    """Time the CPU path on a bounded sample of the same workload: whole rows of the
+    frame, all `spp` samples per pixel, as many rows as ~budget_s of CPU work allows
+    (calibrated on a thin slice), spread over the frame.  Uses oracle/_ref (the
+    compiled reference kernel) when that library is present, else the oracle port."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from oracle import Oracle, Reference
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 64))
+    kind = "reference" if Reference.available() else "port"
+    ref = Reference() if kind == "reference" else None
+    orc = Oracle()
+
+    def run(rows_y0, rows, spp):
+        t0 = time.perf_counter()
+        region = (0, rows_y0, wl.width, rows)
+        if ref is not None:
+            ref.progressive(wl.scene, wl.camera, table, wl.width, wl.height, spp, threads, region=region)
+        else:
+            orc.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=spp, region=region, threads=threads)
+        return time.perf_counter() - t0
+
+    # calibrate on `threads` rows through the middle of the frame (sky + scene mix), 1 spp
+    y_mid = wl.height // 2 - threads // 2
+    t_cal = max(run(max(y_mid, 0), min(threads, wl.height), 1), 1e-4)
+    per_sample = t_cal / (wl.width * min(threads, wl.height))          # wall seconds per pixel-sample
+    spp = wl.spp
+    rows = int(budget_s / threads * 1.0 / max(per_sample * wl.width * spp, 1e-9))  # wall budget = budget_s/threads
+    rows = max(threads, min(wl.height, rows // threads * threads))
+    y0 = max(0, (wl.height - rows) // 2)
+    wall = run(y0, rows, spp)
+    samples = wl.width * rows * spp
+    return {"value": round(samples / wall / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": "rows %d..%d of the %dx%d frame, %d spp (%.1f M pixel-samples, %.1f s wall)" %
+                      (y0, y0 + rows - 1, wl.width, wl.height, spp, samples / 1e6, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import opencl_raytracing_amd as rt
+    from importlib import import_module
+    dist_mod = import_module("opencl-raytracing_amd.distributed")
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
+    rank, world, local = dist_mod.init_process_group()
+    if world != args.gpus:
+        sys.exit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" %
+                 (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+
+    wl = rt.workloads.get(args.workload)
+    base_spp = args.spp or wl.spp
+    spp = base_spp * world                       # weak scaling: per-GPU pixel-samples fixed
+    tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=local, seed=rt.workloads.SEED)
+    renderer = dist_mod.ShardedRenderer(tracer, rank, world)
+    table = tracer.getRandomTable() if rank == 0 else None
+
+    def step():
+        renderer.render(wl.camera, spp)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # algorithmic bytes of one launch: exact work counters from the counting build (untimed)
+    tracer.enableCounters(True)
+    tracer.resetCounters()
+    step()
+    tracer.sync()
+    cn = tracer.counters()
+    tracer.enableCounters(False)
+    alg_bytes = cn.algorithmic_bytes()
+    my_samples = cn.samples
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    wall = time.perf_counter() - t0
+    # per-launch kernel duration over the timed region: the library records a HIP event
+    # pair on the launch stream around every trace launch; read them back afterwards
+    ev_ms = tracer.kernelMsHistory(min(args.steps, 64))
+    launch_ms = float(np.mean(ev_ms))
+
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    s = torch.tensor([float(my_samples)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    wall_max, total_samples = float(t.item()), float(s.item())
+
+    if rank == 0:
+        ms_per_step = wall_max / args.steps * 1e3
+        value = total_samples * args.steps / wall_max / 1e6
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec (rays/sec) at 1920x1080, 64 spp; % HBM roofline",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD_DESC[args.workload], "width": wl.width, "height": wl.height,
+                       "spp_per_gpu": base_spp, "spp_total": spp, "sharding": "8x8 tiles interleaved over %d rank(s)"
+                       % world + ("; RCCL reduce of the radiance buffer to rank 0" if world > 1 else ""),
+                       "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "pt_render<MODE_ACCUM>", "kernel_ms": round(launch_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "bytes_per_pixel_sample": round(alg_bytes / max(my_samples, 1), 1),
+                         "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3)},
+            "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tracer.close()
+
+
+if __name__ == "__main__":
+    main()

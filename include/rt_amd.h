@@ -312,8 +312,12 @@ int rt_get_counters(rt_context *ctx, rt_counters *out);
 uint64_t rt_counters_bytes(const rt_counters *c);
 
 /* Milliseconds the last render call's kernel(s) took on the device
- * (hipEvent pair on the launch stream). */
+ * (hipEvent pair recorded on the launch stream around the launch). */
 int rt_last_kernel_ms(rt_context *ctx, float *ms);
+
+/* The same for the last *n_out <= min(cap, 64) render calls, oldest first.  The
+ * events are only read here, so a timed loop can run without per-step syncs. */
+int rt_kernel_ms_history(rt_context *ctx, float *ms, size_t cap, size_t *n_out);
 
 /* Name, CU count and arch of the context's device, e.g. "gfx950". */
 int rt_device_info(rt_context *ctx, char *name, size_t name_len, int *cu_count, char *arch, size_t arch_len);

@@ -216,8 +216,9 @@ struct rt_context {
     int width = 0, height = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    static constexpr int EV_RING = 64;   // event pairs of the last EV_RING render calls
+    hipEvent_t ev[EV_RING][2] = {};
+    uint64_t ev_count = 0;
     std::string error;
     std::string dev_name, dev_arch;
     int cu_count = 0;
@@ -363,7 +364,8 @@ int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t
     // split very long launches into slot ranges (keeps single kernels short on huge scenes)
     uint32_t slots_per_launch = ctx->max_threads_per_launch >> glog2;
     if (slots_per_launch == 0) slots_per_launch = 1;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipEvent_t *evp = ctx->ev[ctx->ev_count % rt_context::EV_RING];
+    HIP_TRY(ctx, hipEventRecord(evp[0], ctx->stream));
     for (uint32_t b = 0; b < slots; b += slots_per_launch) {
         fp.slot_begin = b;
         fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
@@ -377,8 +379,8 @@ int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t
                                ctx->d_image, ctx->d_counters);
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timed = true;
+    HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));
+    ctx->ev_count++;
     return RT_OK;
 }
 
@@ -440,7 +442,8 @@ int rt_create(int device, int width, int height, rt_context **out) {
     if (hipSetDevice(device) != hipSuccess) { ctx->error = "hipSetDevice failed"; return bail(RT_EHIP); }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->error = "hipStreamCreate failed"; return bail(RT_EHIP); }
     ctx->stream = ctx->own_stream;
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
+    for (int i = 0; i < rt_context::EV_RING; i++)
+        if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
     if (hipMalloc((void **)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
@@ -460,8 +463,9 @@ void rt_destroy(rt_context *ctx) {
     if (ctx->d_image) (void)hipFree(ctx->d_image);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < rt_context::EV_RING; i++)
+        for (int k = 0; k < 2; k++)
+            if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -480,7 +484,7 @@ int rt_set_stream(rt_context *ctx, void *hip_stream) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    ctx->timed = false;
+    ctx->ev_count = 0;
     return RT_OK;
 }
 
@@ -782,13 +786,25 @@ uint64_t rt_counters_bytes(const rt_counters *c) {
            (48 + 16) * c->samples + 16 * c->image_reads;
 }
 
+int rt_kernel_ms_history(rt_context *ctx, float *ms, size_t cap, size_t *n_out) {
+    if (!ctx || !ms || !n_out) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t have = ctx->ev_count < (uint64_t)rt_context::EV_RING ? (size_t)ctx->ev_count : (size_t)rt_context::EV_RING;
+    size_t n = have < cap ? have : cap;
+    for (size_t i = 0; i < n; i++) {  // oldest of the last n first
+        hipEvent_t *evp = ctx->ev[(ctx->ev_count - n + i) % rt_context::EV_RING];
+        HIP_TRY(ctx, hipEventSynchronize(evp[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[i], evp[0], evp[1]));
+    }
+    *n_out = n;
+    return RT_OK;
+}
+
 int rt_last_kernel_ms(rt_context *ctx, float *ms) {
     if (!ctx || !ms) return RT_EINVAL;
-    if (!ctx->timed) return fail(ctx, RT_ESTATE, "no render call has been timed yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-    return RT_OK;
+    if (ctx->ev_count == 0) return fail(ctx, RT_ESTATE, "no render call has been timed yet");
+    size_t n = 0;
+    return rt_kernel_ms_history(ctx, ms, 1, &n);
 }
 
 int rt_device_info(rt_context *ctx, char *name, size_t name_len, int *cu_count, char *arch, size_t arch_len) {

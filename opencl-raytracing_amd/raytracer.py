@@ -26,7 +26,7 @@ SYMBOLS = (
     "rt_set_shard", "rt_render", "rt_render_again", "rt_sample_counter", "rt_clear", "rt_render_spp", "rt_resolve",
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
-    "rt_device_info",
+    "rt_kernel_ms_history", "rt_device_info",
 )
 
 
@@ -84,6 +84,7 @@ def load_library(path=LIB_PATH):
     lib.rt_counters_bytes.argtypes = [C.POINTER(_abi.Counters)]
     lib.rt_counters_bytes.restype = u64
     lib.rt_last_kernel_ms.argtypes = [vp, fp]
+    lib.rt_kernel_ms_history.argtypes = [vp, fp, sz, C.POINTER(sz)]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.c_char_p, sz]
     if lib.rt_abi_version() != _abi.RT_ABI_VERSION:
         raise OSError("librt_amd.so ABI %d != expected %d" % (lib.rt_abi_version(), _abi.RT_ABI_VERSION))
@@ -277,6 +278,13 @@ class RayTracer:
         ms = C.c_float()
         self._check(self._lib.rt_last_kernel_ms(self._ctx, C.byref(ms)))
         return ms.value
+
+    def kernelMsHistory(self, n=64):
+        """Device durations (ms) of the last <= min(n, 64) render launches, oldest first."""
+        buf = (C.c_float * n)()
+        got = C.c_size_t()
+        self._check(self._lib.rt_kernel_ms_history(self._ctx, buf, n, C.byref(got)))
+        return [buf[i] for i in range(got.value)]
 
     def deviceInfo(self):
         name, arch, cu = C.create_string_buffer(128), C.create_string_buffer(64), C.c_int()

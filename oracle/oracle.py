@@ -133,19 +133,29 @@ class Reference(_Base):
     def __init__(self, path=REF_SO):
         self.lib = C.CDLL(path)
 
-    def trace(self, scene, cam, table, w, h, threads=1):
+    def trace(self, scene, cam, table, w, h, threads=1, region=None):
+        x0, y0, cw, ch = region if region else (0, 0, w, h)
         img = np.zeros((h, w, 4), dtype=np.float32)
         sd, tex, tw, th, layers = self._scene_args(scene)
         cam, table = _f32(cam), _f32(table)
-        assert self.lib.ref_trace(_fp(img), w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers, threads) == 0
+        assert self.lib.ref_trace(_fp(img), w, h, x0, y0, cw, ch, _fp(cam), _fp(table), sd, tex, tw, th, layers,
+                                  threads) == 0
         return img
 
-    def retrace(self, image, scene, cam, table, w, h, sample, threads=1):
+    def retrace(self, image, scene, cam, table, w, h, sample, threads=1, region=None):
+        x0, y0, cw, ch = region if region else (0, 0, w, h)
         img = _f32(image).copy()
         sd, tex, tw, th, layers = self._scene_args(scene)
         cam, table = _f32(cam), _f32(table)
-        assert self.lib.ref_retrace(_fp(img), w, h, _fp(cam), _fp(table), sd, tex, tw, th, layers,
+        assert self.lib.ref_retrace(_fp(img), w, h, x0, y0, cw, ch, _fp(cam), _fp(table), sd, tex, tw, th, layers,
                                     C.c_uint32(sample), threads) == 0
+        return img
+
+    def progressive(self, scene, cam, table, w, h, spp, threads=1, region=None):
+        """trace + (spp-1) retrace launches — the reference's render()/renderAgain() sequence."""
+        img = self.trace(scene, cam, table, w, h, threads, region)
+        for s in range(1, spp):
+            img = self.retrace(img, scene, cam, table, w, h, s, threads, region)
         return img
 
     def samples(self, scene, cam, table, w, h, xs, ys, ss):

@@ -263,15 +263,15 @@ void build_scene(RefScene &rs, const rt_scene_desc *d, const float *tex, int tw,
 }
 
 template <class F>
-void parallel_rows(int h, int threads, F f) {
+void parallel_rows(int y0, int h, int threads, F f) {
     if (threads <= 1) {
-        for (int y = 0; y < h; y++) f(y);
+        for (int y = y0; y < y0 + h; y++) f(y);
         return;
     }
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++)
         pool.emplace_back([=]() {
-            for (int y = t; y < h; y += threads) f(y);
+            for (int y = y0 + t; y < y0 + h; y += threads) f(y);
         });
     for (auto &th : pool) th.join();
 }
@@ -280,14 +280,16 @@ void parallel_rows(int h, int threads, F f) {
 
 extern "C" {
 
-// one `trace` launch over the whole frame (global size (W,H)), raytracer.cl:496
-int ref_trace(float *image_rgba, int w, int h, const float *camera, const float *table, const rt_scene_desc *scene,
-              const float *tex, int tw, int th, int layers, int threads) {
+// one `trace` launch (global size (W,H), raytracer.cl:496); only the work-items of
+// the region [x0,x0+cw)×[y0,y0+ch) are executed
+int ref_trace(float *image_rgba, int w, int h, int x0, int y0, int cw, int ch, const float *camera,
+              const float *table, const rt_scene_desc *scene, const float *tex, int tw, int th, int layers,
+              int threads) {
     RefScene rs;
     build_scene(rs, scene, tex, tw, th, layers);
     HostImage img{w, h, 1, image_rgba};
-    parallel_rows(h, threads, [&](int y) {
-        for (int x = 0; x < w; x++) {
+    parallel_rows(y0, ch, threads, [&](int y) {
+        for (int x = x0; x < x0 + cw; x++) {
             g_gid[0] = (size_t)x;
             g_gid[1] = (size_t)y;
             HostImage local = img;
@@ -298,13 +300,14 @@ int ref_trace(float *image_rgba, int w, int h, const float *camera, const float 
 }
 
 // one `retrace` launch, image_in == image_out as in src/raytracer.cpp:114-115
-int ref_retrace(float *image_rgba, int w, int h, const float *camera, const float *table, const rt_scene_desc *scene,
-                const float *tex, int tw, int th, int layers, unsigned sample, int threads) {
+int ref_retrace(float *image_rgba, int w, int h, int x0, int y0, int cw, int ch, const float *camera,
+                const float *table, const rt_scene_desc *scene, const float *tex, int tw, int th, int layers,
+                unsigned sample, int threads) {
     RefScene rs;
     build_scene(rs, scene, tex, tw, th, layers);
     HostImage img{w, h, 1, image_rgba};
-    parallel_rows(h, threads, [&](int y) {
-        for (int x = 0; x < w; x++) {
+    parallel_rows(y0, ch, threads, [&](int y) {
+        for (int x = x0; x < x0 + cw; x++) {
             g_gid[0] = (size_t)x;
             g_gid[1] = (size_t)y;
             HostImage local = img;

@@ -1,0 +1,73 @@
+"""Generate tests/golden/*.npz from the compiled reference kernel (oracle/_ref).
+
+Run in the build container only (needs /root/reference to build oracle/_ref):
+    python tests/golden/gen_golden.py [case ...]
+Every expected value below comes out of the UNMODIFIED reference kernel file
+(compiled for x86-64 by oracle/Makefile) driven through oracle/ref_shim.cpp;
+inputs are the deterministic workloads of opencl-raytracing_amd/workloads.py.
+The fixtures are data (inputs + expected outputs); no reference source is stored.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cases  # noqa: E402
+from oracle import Reference  # noqa: E402
+
+rt = cases.rt
+
+
+def gen_case(name, ref, table, threads=8):
+    c = cases.CASES[name]
+    wl = cases.workload(name)
+    t0 = time.time()
+    out = dict(width=wl.width, height=wl.height, spp=c["spp"], crop=np.array(c["crop"]), camera=wl.camera,
+               seed=np.uint64(cases.SEED), scene_hash=cases.scene_hash(wl, table))
+    # per-sample linear radiance: genInitRay + getCol of the reference
+    xs, ys, ss = cases.probes(name, wl)
+    rgb = ref.samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
+    out.update(probe_x=xs, probe_y=ys, probe_s=ss, probe_rgb_bits=rgb.view(np.uint32))
+    # progressive image (trace + spp-1 retrace) on the crop
+    x0, y0, cw, ch = c["crop"]
+    img = ref.progressive(wl.scene, wl.camera, table, wl.width, wl.height, c["spp"], threads, region=c["crop"])
+    out["crop_rgba_bits"] = np.ascontiguousarray(img[y0:y0 + ch, x0:x0 + cw]).view(np.uint32)
+    # full-frame checksum of one `trace` launch
+    if c["full_frame_spp"]:
+        full = ref.trace(wl.scene, wl.camera, table, wl.width, wl.height, threads)
+        out["full_trace_checksum"] = np.uint64(cases.frame_checksum(full))
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, name + ".npz"), **out)
+    print("%-10s %dx%d probes %d crop %s spp %d  (%.1fs)" % (name, wl.width, wl.height, len(xs), c["crop"], c["spp"],
+                                                             time.time() - t0))
+
+
+def gen_units(ref, n=1000):
+    wl = cases.workload("all_kinds")
+    out = {}
+    for i, kind in enumerate(("sphere", "plane", "lens")):
+        rays, prim, _ = cases.unit_rays(kind, wl.scene, n, 100 + 10 * i)
+        out[kind] = ref.hit(i, wl.scene, rays, prim).view(np.uint32)
+    rays, mesh, face = cases.unit_rays("triangle", wl.scene, n, 140)
+    out["triangle"] = ref.hit_triangle(wl.scene, rays, mesh, face).view(np.uint32)
+    rays, prim, _ = cases.unit_rays("scene", wl.scene, n, 150)
+    hs = ref.hit(3, wl.scene, rays, prim)
+    hs[:, 8:11] = 0  # uv / texture id of non-mesh hits are indeterminate in the reference
+    out["scene"] = hs.view(np.uint32)
+    for k in ("sphere", "plane", "lens", "triangle", "scene"):
+        print("unit %-8s hits %d / %d" % (k, int((out[k].view(np.float32)[:, 0] > 0).sum()), n))
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, "units.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not Reference.available():
+        sys.exit("oracle/_ref/libref.so missing: run `make -C oracle` where /root/reference exists")
+    ref = Reference()
+    table = rt.workloads.make_random_table(cases.SEED)
+    names = sys.argv[1:] or list(cases.CASES) + ["units"]
+    for nm in names:
+        if nm == "units":
+            gen_units(ref)
+        else:
+            gen_case(nm, ref, table)

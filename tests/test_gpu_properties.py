@@ -1,0 +1,148 @@
+"""GPU (-m gpu): size-independent properties at BASELINE.json's full sizes, edge cases
+and error behaviour of the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+rt = cases.rt
+
+
+@pytest.fixture(scope="module")
+def c2_full():
+    wl = cases.workload("c2")
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    yield wl, t
+    t.close()
+
+
+def test_c2_full_size_deterministic_and_probes(c2_full, oracle, table):
+    wl, t = c2_full
+    a = t.renderFrame(wl.camera, wl.spp)
+    b = t.renderFrame(wl.camera, wl.spp)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))          # run-to-run bit-identical
+    assert (a[..., 3] == 1.0).all() and np.isfinite(a).all()
+    assert 0.05 < (a[..., :3].sum(-1) > 0).mean() < 1.0
+    rng = np.random.RandomState(3)
+    n = 6000
+    xs, ys, ss = rng.randint(0, wl.width, n), rng.randint(0, wl.height, n), rng.randint(0, wl.spp, n)
+    got = t.traceSamples(wl.camera, xs, ys, ss)
+    exp, _ = oracle.samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_c2_full_size_sharded_sum_equals_unsharded(c2_full):
+    """Tile sharding (what the N-GPU path does) on one GPU with virtual ranks: the
+    element-wise sum of the ranks' buffers is the unsharded frame, bit for bit."""
+    wl, t = c2_full
+    t.setShard(0, 1, 8, 8)
+    whole_img = t.renderFrame(wl.camera, 16)
+    whole_lin = t.readLinear()
+    for world in (2, 8):
+        acc_img = np.zeros_like(whole_img)
+        acc_lin = np.zeros_like(whole_lin)
+        owned = np.zeros(whole_img.shape[:2], np.int32)
+        for rank in range(world):
+            t.setShard(rank, world, 8, 8)
+            img = t.renderFrame(wl.camera, 16)
+            owned += (img[..., 3] > 0)
+            acc_img += img
+            acc_lin += t.readLinear()
+        assert (owned == 1).all()                       # every pixel owned exactly once
+        assert np.array_equal(acc_img.view(np.uint32), whole_img.view(np.uint32))
+        assert np.array_equal(acc_lin.view(np.uint32), whole_lin.view(np.uint32))
+    t.setShard(0, 1, 8, 8)
+
+
+def test_c2_sample_ranges_compose(c2_full):
+    """Linearity: samples [0,32) then [32,64) accumulate to the same mean as [0,64) (within
+    float summation order), and a second accumulation of the same range doubles the sum."""
+    wl, t = c2_full
+    t.clear(); t.renderSamples(wl.camera, 0, 64); one = t.readLinear()
+    t.clear(); t.renderSamples(wl.camera, 0, 32); t.renderSamples(wl.camera, 32, 32); two = t.readLinear()
+    dev = np.abs(one - two) / np.maximum(np.maximum(np.abs(one), np.abs(two)), 1e-6)
+    assert dev.max() <= 1e-5
+    t.clear(); t.renderSamples(wl.camera, 0, 64); t.renderSamples(wl.camera, 0, 64); twice = t.readLinear()
+    assert np.array_equal(twice.view(np.uint32), one.view(np.uint32))    # (2·sum)/(2·n) == sum/n exactly
+
+
+def test_c3_full_size_256spp(oracle, table):
+    wl = cases.workload("c3")
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    img = t.renderFrame(wl.camera, wl.spp)
+    assert np.isfinite(img).all() and (img[..., :3] <= 1.0 + 1e-6).all()
+    # a 32×24 window through the textured cube against the oracle's progressive result
+    region = (940, 310, 32, 24)
+    exp, _ = oracle.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=wl.spp, region=region, threads=8)
+    x0, y0, cw, ch = region
+    a, b = img[y0:y0 + ch, x0:x0 + cw], exp[y0:y0 + ch, x0:x0 + cw]
+    assert (np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max() <= 1e-4
+    t.close()
+
+
+def test_edge_cases(oracle, table):
+    s = rt.SceneCreator()                                   # empty scene: everything misses → black
+    s.addMaterial(rt._abi.T_DIFFUSE, (1, 1, 1), 1)
+    t = rt.RayTracer(33, 17, scene=s)
+    cam = rt.Camera(60, 33 / 17).transferData()
+    img = t.renderFrame(cam, 3)
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    t.resize(1, 1)                                          # 1×1 frame
+    t.render(cam); t.renderAgain(cam)
+    assert t.transferImage().shape == (1, 1, 4)
+    t.close()
+    wl = rt.workloads.get("all_kinds", width=40, height=24)
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    # largest sample index the API admits
+    xs, ys = np.arange(40) % 40, np.arange(40) % 24
+    ss = np.full(40, 65535)
+    got = t.traceSamples(wl.camera, xs, ys, ss)
+    exp, _ = oracle.samples(wl.scene, wl.camera, table, 40, 24, xs, ys, ss)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    for spp in (1, 2, 63, 65, 130):                         # non-power-of-two sample counts
+        img = t.renderFrame(wl.camera, spp)
+        ref, _ = oracle.render(wl.scene, wl.camera, table, 40, 24, 2, count=spp, threads=8)
+        assert (np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)).max() <= 1e-4, spp
+    # another seed really changes the picture, and an injected table is honoured
+    base = t.renderFrame(wl.camera, 4)
+    t.setSeed(99)
+    other = t.renderFrame(wl.camera, 4)
+    assert not np.array_equal(base, other)
+    t.setRandomTable(table)
+    assert np.array_equal(t.renderFrame(wl.camera, 4).view(np.uint32), base.view(np.uint32))
+    t.close()
+
+
+def test_error_behaviour():
+    lib = rt.load_library()
+    ctx = C.c_void_p()
+    assert lib.rt_create(0, 0, 10, C.byref(ctx)) == -1 and b"frame size" in lib.rt_last_error(None)
+    assert lib.rt_create(99, 8, 8, C.byref(ctx)) == -2
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIFFUSE, (1, 1, 1), 1)
+    s.addSphere((0, 0, 3), 1, 5)                            # material 5 does not exist
+    with pytest.raises(rt.RtError) as e:
+        rt.RayTracer(8, 8, scene=s)
+    assert e.value.code == -5 and "material 5" in str(e.value)
+    wl = rt.workloads.get("c3", width=16, height=16, tex_size=8)
+    wl.scene.textures = None                                # textured model without textures
+    t = rt.RayTracer(16, 16, scene=wl.scene)
+    with pytest.raises(rt.RtError) as e:
+        t.render(wl.camera)
+    assert e.value.code == -5
+    with pytest.raises(rt.RtError):
+        t.setShard(2, 2)                                    # rank out of range
+    with pytest.raises(rt.RtError):
+        t.setShard(0, 1, 6, 8)                              # tile side not a power of two
+    with pytest.raises(rt.RtError):
+        t.renderSamples(wl.camera, 65530, 10)               # beyond RT_MAX_SAMPLE
+    t.close()
+    assert rt.RtError  # render before any scene
+    ctx = C.c_void_p()
+    assert lib.rt_create(0, 8, 8, C.byref(ctx)) == 0
+    cam = (C.c_float * 12)()
+    assert lib.rt_render(ctx, cam) == -4 and b"no scene" in lib.rt_last_error(ctx)
+    lib.rt_destroy(ctx)
