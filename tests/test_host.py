@@ -1,0 +1,174 @@
+"""CPU: host-side logic — scene file grammar, OBJ reader, camera block, C ABI surface
+(symbols, struct layouts, error behaviour without a device)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+
+rt = cases.rt
+ROOT = cases.ROOT
+
+
+def test_abi_exports_every_declared_symbol(built):
+    """librt_amd.so loads and exports every function include/rt_amd.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*\*?\s*(rt_[a-z_0-9]+)\(", hdr, re.M))
+    assert len(declared) >= 30
+    assert declared == set(rt.raytracer.SYMBOLS), declared ^ set(rt.raytracer.SYMBOLS)
+    lib = C.CDLL(rt.LIB_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.rt_abi_version() == 1
+
+
+def test_struct_layouts_match_reference_device_structs():
+    a = rt._abi
+    assert (a.MATERIAL.itemsize, a.SPHERE.itemsize, a.PLANE.itemsize, a.LENS.itemsize, a.MESH.itemsize,
+            a.MODEL.itemsize) == (48, 32, 48, 64, 16, 12)        # SURVEY §8a, verified against the compiled .cl
+    assert a.MATERIAL.fields["color"][1] == 16 and a.MATERIAL.fields["extra_data"][1] == 32
+    assert a.SPHERE.fields["r"][1] == 16 and a.SPHERE.fields["mat_ID"][1] == 20
+    assert a.PLANE.fields["normal"][1] == 16 and a.PLANE.fields["mat_ID"][1] == 32
+    assert a.LENS.fields["p1"][1] == 16 and a.LENS.fields["r1"][1] == 48 and a.LENS.fields["mat_ID"][1] == 56
+    assert C.sizeof(a.SceneDesc) == 9 * 8 + 10 * 4
+    assert C.sizeof(a.Counters) == 14 * 8
+
+
+def test_no_device_means_failure_not_fallback(built):
+    """Without a GPU the product fails loudly: there is no CPU path behind the C ABI."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = rt.load_library()
+    ctx = C.c_void_p()
+    assert lib.rt_create(0, 64, 64, C.byref(ctx)) == -2
+    assert b"no HIP device" in lib.rt_last_error(None) and not ctx.value
+    with pytest.raises(rt.RtError):
+        rt.RayTracer(64, 64)
+
+
+def test_product_never_touches_the_oracle():
+    """No file of the product (package, include/, host/, bench's GPU leg) references oracle/."""
+    pkg = os.path.join(ROOT, "opencl-raytracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in text and "pt_oracle" not in text and "import oracle" not in text and \
+                    "from oracle" not in text, os.path.join(dirpath, f)
+
+
+SCENE_TEXT = """
+# comment line
+MATERIALS:
+diffuse, (1, 0.5, .25), 1   # trailing comment
+light, (1, 1, 1), 0
+SPHERES:
+(0, -1.5, +3), 1.25, 0
+PLANES:
+(0, 5, 0), (0, 1, 0), 1
+LENSES:
+(5, 0, 0), (1, 0, 0), 10, 10, 2, 0
+"""
+
+
+def test_scene_grammar():
+    s = rt.SceneCreator()
+    s.loadSceneText(SCENE_TEXT)
+    assert len(s.materials) == 2 and len(s.spheres) == 1 and len(s.planes) == 1 and len(s.lenses) == 1
+    assert s.materials["type"].tolist() == [rt._abi.T_DIFFUSE, rt._abi.T_LIGHT]
+    assert np.allclose(s.materials["color"][0], [1, 0.5, 0.25, 0])
+    assert np.allclose(s.spheres["pos"][0], [0, -1.5, 3, 0]) and s.spheres["r"][0] == np.float32(1.25)
+    # addLens: p1,p2 = pos ± normal·sqrt(r² − h²)  (src/scene.cpp:122-143)
+    t = np.float32(np.sqrt(np.float32(100 - 4)))
+    assert np.allclose(s.lenses["p1"][0][:3], [5 + t, 0, 0]) and np.allclose(s.lenses["p2"][0][:3], [5 - t, 0, 0])
+    d = s.desc()
+    assert (d.material_count, d.sphere_count, d.plane_count, d.lens_count, d.model_count) == (2, 1, 1, 1, 0)
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("SPHERES:\n(0, 0, 3), 1, 12\n", "IMPROPER UNSIGNED INT"),            # getUInt takes ONE digit (scene.cpp:455)
+    ("SPHERES:\n(0, 0, 3), 1e3, 0\n", "IMPROPER FLOAT"),                  # no exponents (scene.cpp:448)
+    ("SPHERES:\n(0, 0), 1, 0\n", "IMPROPER VECTOR"),
+    ("SPHERES:\n(0, 0, 3), 1\n", "NOT ENOUGH PARAMETERS"),
+    ("MATERIALS:\nshiny, (1, 1, 1), 1\n", "MATERIAL:  shiny DOES NOT EXIST".replace("  ", " ")),
+    ("MATERIALS:\n# nothing\nSPHERES:\n", None),
+    ("SPHERES:\nfoo: 1\n", "OPERATION foo DOES NOT EXIST"),
+    ("LENSES:\n(0, 0, 0), (1, 0, 0), 1, 1, 2, 0\n", "LENS"),
+])
+def test_scene_errors(text, msg):
+    if msg is None:
+        rt.SceneCreator().loadSceneText(text)       # empty sections are fine
+        return
+    with pytest.raises(rt.SceneError) as e:
+        rt.SceneCreator().loadSceneText("MATERIALS:\ndiffuse, (1, 1, 1), 1\n" + text if "MATERIALS" not in text
+                                        else text)
+    assert msg in str(e.value)
+
+
+def test_scene_line_before_any_section():
+    with pytest.raises(rt.SceneError) as e:
+        rt.SceneCreator().loadSceneText("(0, 0, 3), 1, 0\n")
+    assert "OPERATION NOT SPECIFIED" in str(e.value)
+
+
+def test_model_ops_and_obj_reader():
+    """translate/rotate/scale post-multiply (glm), reset after load; one vertex per face corner,
+    fan triangulation, v → 1−v (what Assimp's Triangulate|FlipUVs produces, src/scene.cpp:195)."""
+    s = rt.SceneCreator()
+    s.loadScene(os.path.join(ROOT, "assets", "scenes", "all_kinds.scene"), base_dir=os.path.join(ROOT, "assets"))
+    assert len(s.models) == 2 and len(s.meshes) == 2
+    assert s.models["mesh_anchor"].tolist() == [0, 1] and s.models["mat_ID"].tolist() == [2, 2]
+    assert s.meshes["face_count"].tolist() == [12, 12]
+    assert s.meshes["vertex_anchor"].tolist() == [0, 24] and s.meshes["index_anchor"].tolist() == [0, 36]
+    assert len(s.vertices) == 48 and len(s.texture_uv) == 48 and len(s.indices) == 72
+    assert s.indices[:6].tolist() == [0, 1, 2, 0, 2, 3]
+    assert s.texture_paths == ["textures/checker_a.png", "textures/checker_b.png"]
+    assert s.meshes["texture_ID"].tolist() == [0, 1]
+    # first box: rotate 40° about y then scale 1.1 → every vertex at distance 1.1·sqrt(3) from the origin
+    r = np.linalg.norm(s.vertices[:24, :3].astype(np.float64), axis=1)
+    assert np.allclose(r, 1.1 * np.sqrt(3), atol=1e-5)
+    # second box: translate then rotate → centred on the translation
+    assert np.allclose(s.vertices[24:, :3].mean(0), [-6.2, 0.6, 0.2], atol=1e-5)
+    # all faces counter-clockwise seen from outside (hitMeshOut's assumption, raytracer.cl:284)
+    for m in range(2):
+        v = s.vertices[s.meshes["vertex_anchor"][m]:][:24, :3].astype(np.float64)
+        c = v.mean(0)
+        tri = v[s.indices[36 * m:36 * m + 36]].reshape(12, 3, 3)
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        assert (np.einsum("ij,ij->i", n, tri.mean(1) - c) > 0).all()
+    assert s.texture_uv.min() >= 0 and s.texture_uv.max() <= 1
+
+
+def test_camera_block():
+    cam = rt.Camera(60, 1.5)
+    d = cam.transferData()
+    assert d.dtype == np.float32 and d.shape == (12,)
+    hh = np.tan(np.pi / 6)
+    # yaw = pitch = 0: w = +z, u = +x, v = −y, so the lower-left corner has y = +hh (SURVEY §8a "image")
+    assert np.allclose(d[0:3], 0) and np.allclose(d[3:6], [-1.5 * hh, hh, 1], atol=1e-6)
+    assert np.allclose(d[6:9], [3 * hh, 0, 0], atol=1e-6) and np.allclose(d[9:12], [0, -2 * hh, 0], atol=1e-6)
+    cam.setFasterSpeed(True)
+    cam.move(rt.camera.FORWARD, 2.0)
+    assert np.allclose(cam.transferData()[0:3], [0, 0, 10])
+    cam.rotate(10, 500)                                   # pitch is clamped to ±89°
+    assert cam.pitch == np.float32(89.0)
+    cam.zoom(1000)                                        # fov clamped to [10, 90]
+    assert cam.fov == np.float32(90.0)
+    cam.setSize(2.0)
+    assert np.isclose(cam.half_width, 2.0 * cam.half_height)
+
+
+def test_workload_shapes():
+    w = rt.workloads
+    assert len(w.get("c2").scene.spheres) == 8 and len(w.get("c2").scene.planes) == 1
+    c3 = w.get("c3", tex_size=16)
+    assert c3.scene.meshes["face_count"].tolist() == [12] and len(c3.scene.spheres) == 4
+    c4 = w.get("c4")
+    assert len(c4.scene.spheres) == 100000 and c4.scene.spheres.nbytes == 3200000
+    c5 = w.get("c5")
+    assert int(c5.scene.meshes["face_count"][0]) == 50000 and (c5.width, c5.height, c5.spp) == (3840, 2160, 512)
+    assert [w.get(n).spp for n in ("c1", "c2", "c3", "c4")] == [1, 64, 256, 64]
