@@ -39,6 +39,19 @@ WORKLOAD_DESC = {
 }
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if one is set (the GPU box gives 16 cores
+    of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(wl, table, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload: whole rows of the
     frame, all `spp` samples per pixel, as many rows as ~budget_s of CPU work allows
@@ -47,34 +60,39 @@ def cpu_baseline(wl, table, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     from oracle import Oracle, Reference
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, 64))
+    threads = host_cores()
     kind = "reference" if Reference.available() else "port"
     ref = Reference() if kind == "reference" else None
     orc = Oracle()
 
-    def run(rows_y0, rows, spp):
+    def run(bands, rows, spp):
+        """`rows` consecutive rows starting at each y in `bands`, all columns, `spp` samples."""
         t0 = time.perf_counter()
-        region = (0, rows_y0, wl.width, rows)
-        if ref is not None:
-            ref.progressive(wl.scene, wl.camera, table, wl.width, wl.height, spp, threads, region=region)
-        else:
-            orc.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=spp, region=region, threads=threads)
+        for y in bands:
+            region = (0, y, wl.width, rows)
+            if ref is not None:
+                ref.progressive(wl.scene, wl.camera, table, wl.width, wl.height, spp, threads, region=region)
+            else:
+                orc.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=spp, region=region,
+                           threads=threads)
         return time.perf_counter() - t0
 
-    # calibrate on `threads` rows through the middle of the frame (sky + scene mix), 1 spp
-    y_mid = wl.height // 2 - threads // 2
-    t_cal = max(run(max(y_mid, 0), min(threads, wl.height), 1), 1e-4)
-    per_sample = t_cal / (wl.width * min(threads, wl.height))          # wall seconds per pixel-sample
+    # bands of `threads` rows spread evenly from top to bottom of the frame (sky, horizon,
+    # floor all represented); calibrate at 1 spp, then size the band count to the budget
+    rows = min(threads, wl.height)
+    max_bands = max(1, wl.height // rows)
+    cal_bands = [int(i * (wl.height - rows) / 7) for i in range(8)] if max_bands >= 8 else [0]
+    t_cal = max(run(cal_bands, rows, 1), 1e-4)
+    per_sample_cpu = t_cal * threads / (wl.width * rows * len(cal_bands))   # core-seconds per pixel-sample
     spp = wl.spp
-    rows = int(budget_s / threads * 1.0 / max(per_sample * wl.width * spp, 1e-9))  # wall budget = budget_s/threads
-    rows = max(threads, min(wl.height, rows // threads * threads))
-    y0 = max(0, (wl.height - rows) // 2)
-    wall = run(y0, rows, spp)
-    samples = wl.width * rows * spp
+    n_bands = int(budget_s / max(per_sample_cpu * wl.width * rows * spp, 1e-9))
+    n_bands = max(1, min(max_bands, n_bands))
+    bands = [int(i * (wl.height - rows) / max(n_bands - 1, 1)) for i in range(n_bands)]
+    wall = run(bands, rows, spp)
+    samples = wl.width * rows * n_bands * spp
     return {"value": round(samples / wall / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": "rows %d..%d of the %dx%d frame, %d spp (%.1f M pixel-samples, %.1f s wall)" %
-                      (y0, y0 + rows - 1, wl.width, wl.height, spp, samples / 1e6, wall)}
+            "sample": "%d band(s) of %d rows spread over the %dx%d frame, %d spp = %.1f M pixel-samples, %.1f s wall"
+                      % (n_bands, rows, wl.width, wl.height, spp, samples / 1e6, wall)}
 
 
 def main():
