@@ -297,6 +297,14 @@ int rt_read_linear(rt_context *ctx, float *rgba, size_t bytes);
 int rt_device_image(rt_context *ctx, void **d_rgba);
 int rt_device_accum(rt_context *ctx, void **d_rgba);
 
+/* Tuning / diagnostics switches (new).  Results never depend on them. */
+#define RT_OPT_PREFIX_SHARING 1         /* 1 (default): rt_render_spp traces the sample-invariant path
+                                           prefix once per pixel; 0: every sample from the camera      */
+#define RT_OPT_MAX_THREADS_PER_LAUNCH 2 /* split one render call into several kernel launches           */
+#define RT_OPT_SAMPLE_QUEUE 3           /* 1 (default): lanes pull samples from an in-wave queue as their
+                                           paths end; 0: one fixed sample set per lane                  */
+int rt_set_option(rt_context *ctx, int option, int value);
+
 /* ---- measurement --------------------------------------------------------- */
 
 /* When enabled, render calls run the counting build of the kernel (slower)

@@ -7,14 +7,17 @@
 // IEEE-754 binary32 operation in the reference's evaluation order.  This file
 // must be compiled with -ffp-contract=off and without any fast-math flag.
 //
-// Mapping to the hardware (DESIGN.md §kernels):
-//   * one work-item per pixel-sample; the 64 lanes of a wave are 64 samples of
-//     one pixel (or 64/g pixels × g samples), so primitive indices are
-//     wave-uniform: primitive records are fetched with SCALAR loads (s_load,
-//     scalar cache → L2) and cost no VGPRs and no LDS bandwidth;
+// Mapping to the hardware (DESIGN.md §5):
+//   * the 64 lanes of a wave are 64 samples of one pixel (or 64/g pixels × g
+//     samples), so primitive indices are wave-uniform: primitive records are
+//     fetched with SCALAR loads (s_load → scalar cache → L2), four spheres per
+//     batch with the next batch prefetched, and cost no VGPRs and no LDS traffic;
+//   * materials (per-lane index) are staged in LDS once per workgroup;
 //   * the nearest-hit search keeps only (t, id) per lane and rebuilds the hit
 //     record of the winner afterwards (same arithmetic → same bits);
-//   * table / texture gathers are the only divergent memory accesses.
+//   * every material kind ends in ONE shared "new direction" tail, so lanes on
+//     different materials do not serialise a normalize() each;
+//   * table / texture gathers are the only divergent global-memory accesses.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,6 +34,7 @@ struct V3 {
 
 PT_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
 PT_DEV V3 ld3(const rt_float3 &f) { return V3{f.x, f.y, f.z}; }
+PT_DEV V3 xyz(float4 f) { return V3{f.x, f.y, f.z}; }
 PT_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 PT_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 PT_DEV V3 operator*(V3 a, float k) { return V3{a.x * k, a.y * k, a.z * k}; }
@@ -56,12 +60,16 @@ struct Ray {
 };
 PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 
+#define PT_LDS_MATERIALS 64  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
+#define PT_SPHERE_BATCH 4
+
 // Everything the kernels read.  Passed by value (kernarg segment → SGPRs); this
 // replaces the reference's device-resident Scene struct and its createScene
 // pointer-stashing kernel (:74-91, :541-558).
 struct DeviceScene {
     const rt_material *materials;
     const rt_sphere *spheres;
+    const float4 *sph4;  // (cx, cy, cz, r*r) per sphere, padded to whole batches + one dummy batch
     const rt_plane *planes;
     const rt_lens *lenses;
     const rt_float3 *vertices;
@@ -69,10 +77,10 @@ struct DeviceScene {
     const uint32_t *indices;
     const rt_mesh *meshes;
     const rt_model *models;
-    const float *table;   // 400 000 floats
-    const float4 *tex;    // layers × h × w texels
+    const float *table;  // 400 000 floats
+    const float4 *tex;   // layers × h × w texels
     int tex_w, tex_h, tex_layers;
-    uint32_t sphere_count, plane_count, lens_count, model_count;
+    uint32_t material_count, sphere_count, sphere_batches, plane_count, lens_count, model_count;
 };
 
 // per-lane work counters (only in COUNT builds)
@@ -83,6 +91,40 @@ enum {
     CN_SAMPLES, CN_BOUNCES, CN_T_SPHERE, CN_T_PLANE, CN_T_LENS, CN_T_MODEL, CN_T_MESH, CN_T_TRI, CN_H_TRI,
     CN_H_BOUNCE, CN_N_SCATTER, CN_N_DIELECTRIC, CN_N_TEXFETCH, CN_IMAGE_READS
 };
+
+// What a device function needs besides the scene: the workgroup's LDS copy of
+// the materials and the lane's counters.
+struct Ctx {
+    const DeviceScene &sc;
+    const float4 *lmat;  // LDS: [2i] = (r,g,b,extra), [2i+1].x = type bits; nullptr → read global
+    LaneCounters *cn;
+};
+
+// ---- materials in LDS ----------------------------------------------------------
+// call at kernel start by every thread of the workgroup (contains a barrier)
+PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
+    if (sc.material_count > PT_LDS_MATERIALS) return nullptr;
+    for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
+        const rt_material &m = sc.materials[i];
+        lds[2 * i] = make_float4(m.color.x, m.color.y, m.color.z, m.extra_data);
+        lds[2 * i + 1] = make_float4(__int_as_float(m.type), 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    return lds;
+}
+PT_DEV void load_material(const Ctx &c, uint32_t id, int &type, float &extra, V3 &col) {
+    if (c.lmat) {
+        float4 a = c.lmat[2 * id];
+        type = __float_as_int(c.lmat[2 * id + 1].x);
+        extra = a.w;
+        col = mk(a.x, a.y, a.z);
+    } else {
+        const rt_material &m = c.sc.materials[id];
+        type = m.type;
+        extra = m.extra_data;
+        col = ld3(m.color);
+    }
+}
 
 // ---- table index (:113-125) --------------------------------------------------
 // fp64 hash of the direction; the index sum is below 2^32 for w,h <= RT_MAX_DIM
@@ -105,20 +147,14 @@ PT_DEV float random_u(const float *__restrict__ table, V3 dir, uint32_t s_seed, 
 // ---- nearest-hit search --------------------------------------------------------
 // id of the winning primitive: kind in the top 2 bits
 enum : uint32_t { K_SPHERE = 0u << 30, K_PLANE = 1u << 30, K_LENS = 2u << 30, K_MESH = 3u << 30, K_MASK = 3u << 30 };
+#define PT_NO_HIT 0xFFFFFFFFu
 
-struct Best {
-    float t;       // nearest t so far (starts at MAX_DISTANCE)
-    uint32_t id;   // kind | index (sphere/plane/lens index, or mesh index for K_MESH)
-    uint32_t face; // K_MESH: face index inside the mesh
-    uint32_t mat;  // K_MESH: material of the owning model
-    float u, v;    // K_MESH: barycentrics of the hit
-};
-
-// :149-174 — returns the accepted root or a negative number
-PT_DEV float sphere_t(const Ray &r, V3 c, float rad) {
-    V3 oc = c - r.o;
+// :149-174 with r² precomputed (same float product, computed once at upload).
+// Returns the accepted root, or a negative number.
+PT_DEV float sphere_t(const Ray &r, float4 s) {
+    V3 oc = xyz(s) - r.o;
     float b = dot(oc, r.d);
-    float cc = dot(oc, oc) - rad * rad;
+    float cc = dot(oc, oc) - s.w;
     float dis = b * b - cc;
     float t = -1.0f;
     if (dis > 0) {
@@ -134,11 +170,10 @@ PT_DEV float sphere_t(const Ray &r, V3 c, float rad) {
 }
 
 // :176-194
-PT_DEV float plane_t(const Ray &r, V3 p0, V3 n, float *a_out) {
+PT_DEV float plane_t(const Ray &r, V3 p0, V3 n) {
     float a = dot(r.d, n);
     float b = dot(p0 - r.o, n);
     float t = b / a;
-    *a_out = a;
     return in_range(t) ? t : -1.0f;
 }
 
@@ -192,7 +227,7 @@ PT_DEV float triangle_t(const Ray &r, V3 A, V3 e1, V3 e2, float *u_out, float *v
 
 struct Hit {
     V3 p, n;
-    float u, v;     // texture coordinates (mesh hits)
+    float u, v;  // texture coordinates (mesh hits)
     uint32_t tex;
     uint32_t mat;
 };
@@ -202,55 +237,61 @@ struct Hit {
 // primitive keeps a tie); inside a mesh the FIRST front-facing hit in face
 // order wins, not the nearest.
 template <bool COUNT>
-PT_DEV bool hit_scene(const DeviceScene &sc, const Ray &r, Hit &hit, LaneCounters *cn) {
-    Best best;
-    best.t = RT_MAX_DISTANCE;
-    best.id = 0xFFFFFFFFu;
-    best.face = 0;
-    best.mat = 0;
-    best.u = best.v = 0.0f;
+PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
+    const DeviceScene &sc = c.sc;
+    float best_t = RT_MAX_DISTANCE;
+    uint32_t best_id = PT_NO_HIT;
+    uint32_t best_face = 0, best_mat = 0;
+    float best_u = 0.0f, best_v = 0.0f;
 
-    for (uint32_t i = 0; i < sc.sphere_count; i++) {
-        const rt_sphere &s = sc.spheres[i];  // wave-uniform index → scalar loads
-        float t = sphere_t(r, ld3(s.pos), s.r);
-        if (t > 0.0f && t < best.t) {
-            best.t = t;
-            best.id = K_SPHERE | i;
+    // spheres: wave-uniform index → scalar loads; a batch of 4 in flight while 4 are tested
+    if (sc.sphere_batches) {
+        const float4 *sp = sc.sph4;
+        float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
+        for (uint32_t b = 0; b < sc.sphere_batches; b++) {
+            sp += PT_SPHERE_BATCH;  // the array ends with one dummy batch, so this prefetch is always in bounds
+            float4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
+            uint32_t i = b * PT_SPHERE_BATCH;
+            float t;
+            t = sphere_t(r, a0); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | i; }
+            t = sphere_t(r, a1); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 1); }
+            t = sphere_t(r, a2); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 2); }
+            t = sphere_t(r, a3); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 3); }
+            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
         }
     }
     for (uint32_t i = 0; i < sc.plane_count; i++) {
         const rt_plane &p = sc.planes[i];
-        float a;
-        float t = plane_t(r, ld3(p.pos), ld3(p.normal), &a);
-        if (t > 0.0f && t < best.t) {
-            best.t = t;
-            best.id = K_PLANE | i;
+        float t = plane_t(r, ld3(p.pos), ld3(p.normal));
+        if (t > 0.0f && t < best_t) {
+            best_t = t;
+            best_id = K_PLANE | i;
         }
     }
     for (uint32_t i = 0; i < sc.lens_count; i++) {
         int which;
         float t = lens_t(r, sc.lenses[i], &which);
-        if (t > 0.0f && t < best.t) {
-            best.t = t;
-            best.id = K_LENS | i;
+        if (t > 0.0f && t < best_t) {
+            best_t = t;
+            best_id = K_LENS | i;
         }
     }
     for (uint32_t mo = 0; mo < sc.model_count; mo++) {
         const rt_model &model = sc.models[mo];
         float model_best = RT_MAX_DISTANCE;  // hitModel's own hit_min (:307)
-        bool model_hit = false;
-        Best cand = best;
+        uint32_t m_id = PT_NO_HIT, m_face = 0;
+        float m_u = 0.0f, m_v = 0.0f;
         for (uint32_t k = 0; k < model.mesh_count; k++) {
             uint32_t mi = model.mesh_anchor + k;
             const rt_mesh &mesh = sc.meshes[mi];
-            if (COUNT) cn->c[CN_T_MESH]++;
+            if (COUNT) c.cn->c[CN_T_MESH]++;
             // hitMeshOut: scan faces until this lane has its first front-facing hit
             bool found = false;
             float ft = 0.0f, fu = 0.0f, fv = 0.0f;
             uint32_t fface = 0;
             for (uint32_t f = 0; f < mesh.face_count; f++) {
                 if (found) continue;  // this lane is done with the mesh; others keep scanning
-                if (COUNT) cn->c[CN_T_TRI]++;
+                if (COUNT) c.cn->c[CN_T_TRI]++;
                 const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * f;
                 V3 A = ld3(sc.vertices[mesh.vertex_anchor + ib[0]]);
                 V3 B = ld3(sc.vertices[mesh.vertex_anchor + ib[1]]);
@@ -259,7 +300,7 @@ PT_DEV bool hit_scene(const DeviceScene &sc, const Ray &r, Hit &hit, LaneCounter
                 float u, v;
                 float t = triangle_t(r, A, e1, e2, &u, &v);
                 if (t > 0.0f) {
-                    if (COUNT) cn->c[CN_H_TRI]++;
+                    if (COUNT) c.cn->c[CN_H_TRI]++;
                     V3 n = normalize(cross(e1, e2));
                     if (dot(n, r.d) < 0.0f) {
                         found = true;
@@ -269,96 +310,76 @@ PT_DEV bool hit_scene(const DeviceScene &sc, const Ray &r, Hit &hit, LaneCounter
             }
             if (found && ft < model_best) {
                 model_best = ft;
-                model_hit = true;
-                cand.t = ft;
-                cand.id = K_MESH | mi;
-                cand.face = fface;
-                cand.mat = model.mat_ID;
-                cand.u = fu;
-                cand.v = fv;
+                m_id = K_MESH | mi;
+                m_face = fface;
+                m_u = fu;
+                m_v = fv;
             }
         }
-        if (model_hit && cand.t < best.t) best = cand;
+        if (m_id != PT_NO_HIT && model_best < best_t) {
+            best_t = model_best;
+            best_id = m_id;
+            best_face = m_face;
+            best_mat = model.mat_ID;
+            best_u = m_u;
+            best_v = m_v;
+        }
     }
 
     if (COUNT) {
-        cn->c[CN_BOUNCES]++;
-        cn->c[CN_T_SPHERE] += sc.sphere_count;
-        cn->c[CN_T_PLANE] += sc.plane_count;
-        cn->c[CN_T_LENS] += sc.lens_count;
-        cn->c[CN_T_MODEL] += sc.model_count;
+        c.cn->c[CN_BOUNCES]++;
+        c.cn->c[CN_T_SPHERE] += sc.sphere_count;
+        c.cn->c[CN_T_PLANE] += sc.plane_count;
+        c.cn->c[CN_T_LENS] += sc.lens_count;
+        c.cn->c[CN_T_MODEL] += sc.model_count;
     }
-    if (best.id == 0xFFFFFFFFu) return false;
+    if (best_id == PT_NO_HIT) return false;
 
     // rebuild the winner's record with the reference's arithmetic
-    uint32_t kind = best.id & K_MASK, idx = best.id & ~K_MASK;
-    hit.p = point_at(r, best.t);
+    uint32_t kind = best_id & K_MASK, idx = best_id & ~K_MASK;
+    hit.p = point_at(r, best_t);
     hit.u = hit.v = 0.0f;
     hit.tex = 0;
-    if (kind == K_SPHERE) {
-        const rt_sphere &s = sc.spheres[idx];
-        hit.n = (hit.p - ld3(s.pos)) / s.r;  // :160
-        hit.mat = s.mat_ID;
-    } else if (kind == K_PLANE) {
+    if (kind == K_PLANE) {
         const rt_plane &p = sc.planes[idx];
         V3 n = ld3(p.normal);
         hit.n = neg(n) * sign1(dot(r.d, n));  // :187
         hit.mat = p.mat_ID;
-    } else if (kind == K_LENS) {
-        const rt_lens &l = sc.lenses[idx];
-        int which = 0;
-        (void)lens_t(r, l, &which);
-        hit.n = which == 0 ? (hit.p - ld3(l.p1)) / l.r1 : (hit.p - ld3(l.p2)) / l.r2;  // :248
-        hit.mat = l.mat_ID;
-    } else {
+    } else if (kind == K_MESH) {
         const rt_mesh &mesh = sc.meshes[idx];
-        const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * best.face;
+        const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * best_face;
         uint32_t ia = mesh.vertex_anchor + ib[0], ibx = mesh.vertex_anchor + ib[1], ic = mesh.vertex_anchor + ib[2];
         V3 A = ld3(sc.vertices[ia]), B = ld3(sc.vertices[ibx]), C = ld3(sc.vertices[ic]);
         hit.n = normalize(cross(B - A, C - A));  // :285
         rt_float2 ua = sc.uvs[ia], ub = sc.uvs[ibx], uc = sc.uvs[ic];
-        float wgt = 1.0f - best.u - best.v;  // :102
-        hit.u = (ua.x * wgt + ub.x * best.u) + uc.x * best.v;
-        hit.v = (ua.y * wgt + ub.y * best.u) + uc.y * best.v;
+        float wgt = 1.0f - best_u - best_v;  // :102
+        hit.u = (ua.x * wgt + ub.x * best_u) + uc.x * best_v;
+        hit.v = (ua.y * wgt + ub.y * best_u) + uc.y * best_v;
         hit.tex = mesh.texture_ID;
-        hit.mat = best.mat;
+        hit.mat = best_mat;
+    } else {
+        // sphere and lens share normal = (p - centre) / radius (:160, :248)
+        V3 centre;
+        float rad;
+        if (kind == K_SPHERE) {
+            const rt_sphere &s = sc.spheres[idx];
+            centre = ld3(s.pos);
+            rad = s.r;
+            hit.mat = s.mat_ID;
+        } else {
+            const rt_lens &l = sc.lenses[idx];
+            int which = 0;
+            (void)lens_t(r, l, &which);
+            centre = which == 0 ? ld3(l.p1) : ld3(l.p2);
+            rad = which == 0 ? l.r1 : l.r2;
+            hit.mat = l.mat_ID;
+        }
+        hit.n = (hit.p - centre) / rad;
     }
     return true;
 }
 
 // ---- materials -------------------------------------------------------------------
-// :362-367
-PT_DEV void reflect(Ray &r, V3 &c, const Hit &h, V3 n, int type, float extra) {
-    r.o = h.p;
-    float k = 2.0f * dot(r.d, n);
-    r.d = normalize(r.d - n * k);
-    if (type == RT_REFLECTIVE) c = c * extra;
-}
-
-// shared front of :369-381 / :407-418
-PT_DEV void facing(const Ray &r, const Hit &h, float extra, V3 &n, float &ratio, float &cai) {
-    cai = dot(r.d, h.n);
-    if (cai > 0) {
-        n = neg(h.n);
-        ratio = extra;
-        cai = -cai;
-    } else {
-        n = h.n;
-        ratio = 1.0f / extra;
-    }
-}
-
-// :382-386 / :424-429 — the refracted direction is not renormalised
-PT_DEV bool try_refract(Ray &r, const Hit &h, V3 n, float ratio, float cai) {
-    float disc = 1.0f - ratio * ratio * (1.0f - cai * cai);
-    if (disc > 0.0f) {
-        r.o = h.p;
-        r.d = r.d * ratio - n * (ratio * cai + sqrtf(disc));
-        return true;
-    }
-    return false;
-}
-
 // :401-405
 PT_DEV float schlick(float cosine, float ratio) {
     float r0 = (1.0f - ratio) / (1.0f + ratio);
@@ -389,51 +410,87 @@ PT_DEV V3 texture_rgb(const DeviceScene &sc, float s, float t, uint32_t tex_id) 
               ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z);
 }
 
-// :444-486 getCol — colour mixing is min(), the sky is black, a path that
-// survives DEPTH bounces returns what it has.
+// One material interaction at a hit whose material is NOT a light
+// (:454-479 with rayScatter :393, rayReflect :362, rayRefract :369,
+// rayRefractDielectric :407).  `col` is the material colour, or the texel for
+// t_textured.  All kinds end in the same tail: new origin = hit point, new
+// direction = v, normalised unless it is a refraction (:386,:428 do not
+// renormalise).
 template <bool COUNT>
-PT_DEV V3 radiance(const DeviceScene &sc, Ray r, uint32_t sample, uint32_t gx, uint32_t gy, LaneCounters *cn) {
-    V3 out = mk(1.0f, 1.0f, 1.0f);
-    for (uint32_t i = 0; i < RT_DEPTH; i++) {
-        Hit h;
-        if (!hit_scene<COUNT>(sc, r, h, cn)) return mk(0.0f, 0.0f, 0.0f);
-        if (COUNT) cn->c[CN_H_BOUNCE]++;
-        const rt_material &m = sc.materials[h.mat];  // per-lane index → vector loads
-        int type = m.type;
-        float extra = m.extra_data;
-        V3 col = ld3(m.color);
-        if (type == RT_LIGHT) return vmin(out, col);
-        if (type == RT_DIFFUSE || type == RT_TEXTURED) {  // :393-399 rayScatter
-            if (COUNT) cn->c[CN_N_SCATTER]++;
-            V3 rv = random_vec(sc.table, r.d, i + sample, gx, gy);
-            r.d = normalize(h.n + rv);
-            r.o = h.p;
-            out = out * extra;
-            if (type == RT_TEXTURED) {
-                if (COUNT) cn->c[CN_N_TEXFETCH]++;
-                col = texture_rgb(sc, h.u, h.v, h.tex);
-            }
-        } else if (type == RT_REFLECTIVE) {
-            reflect(r, out, h, h.n, type, extra);
-        } else if (type == RT_REFRACTIVE) {  // :369-391
-            V3 n;
-            float ratio, cai;
-            facing(r, h, extra, n, ratio, cai);
-            if (!try_refract(r, h, n, ratio, cai)) reflect(r, out, h, n, type, extra);
-        } else if (type == RT_DIELECTRIC) {  // :407-435
-            if (COUNT) cn->c[CN_N_DIELECTRIC]++;
-            V3 n;
-            float ratio, cai;
-            facing(r, h, extra, n, ratio, cai);
-            float prob = schlick(-cai, ratio);
-            float rnd = random_u(sc.table, r.d, i + sample, gx, gy);
-            if (!(prob < rnd && try_refract(r, h, n, ratio, cai))) reflect(r, out, h, n, type, extra);
+PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, uint32_t seed,
+                    uint32_t gx, uint32_t gy) {
+    V3 v;
+    bool renorm = true;
+    if (type == RT_DIFFUSE || type == RT_TEXTURED) {
+        if (COUNT) c.cn->c[CN_N_SCATTER]++;
+        V3 rv = random_vec(c.sc.table, r.d, seed, gx, gy);
+        v = h.n + rv;
+        out = out * extra;
+    } else if (type == RT_REFLECTIVE) {
+        float k = 2.0f * dot(r.d, h.n);
+        v = r.d - h.n * k;
+        out = out * extra;  // :366 — only for t_reflective
+    } else if (type == RT_REFRACTIVE || type == RT_DIELECTRIC) {
+        V3 n;
+        float ratio;
+        float cai = dot(r.d, h.n);  // cos of the incident angle
+        if (cai > 0) {
+            n = neg(h.n);
+            ratio = extra;
+            cai = -cai;
         } else {
-            continue;  // unknown type: the reference's switch has no default (rejected by rt_set_scene)
+            n = h.n;
+            ratio = 1.0f / extra;
         }
-        out = vmin(out, col);
+        bool want = true;
+        if (type == RT_DIELECTRIC) {
+            if (COUNT) c.cn->c[CN_N_DIELECTRIC]++;
+            float prob = schlick(-cai, ratio);
+            float rnd = random_u(c.sc.table, r.d, seed, gx, gy);
+            want = prob < rnd;
+        }
+        float disc = 1.0f - ratio * ratio * (1.0f - cai * cai);
+        if (want && disc > 0.0f) {
+            v = r.d * ratio - n * (ratio * cai + sqrtf(disc));
+            renorm = false;
+        } else {  // (total internal) reflection about the facing normal
+            float k = 2.0f * dot(r.d, n);
+            v = r.d - n * k;
+        }
+    } else {
+        return;  // unknown type: the reference's switch has no default (rejected by rt_set_scene)
+    }
+    r.o = h.p;
+    if (renorm) v = normalize(v);
+    r.d = v;
+    out = vmin(out, col);  // mixCol is min(), :437
+}
+
+// :444-486 getCol from bounce i0 on — the sky is black, a path that survives
+// DEPTH bounces returns what it has.
+template <bool COUNT>
+PT_DEV V3 trace_from(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t sample, uint32_t gx, uint32_t gy) {
+    for (uint32_t i = i0; i < RT_DEPTH; i++) {
+        Hit h;
+        if (!hit_scene<COUNT>(c, r, h)) return mk(0.0f, 0.0f, 0.0f);
+        if (COUNT) c.cn->c[CN_H_BOUNCE]++;
+        int type;
+        float extra;
+        V3 col;
+        load_material(c, h.mat, type, extra, col);
+        if (type == RT_LIGHT) return vmin(out, col);
+        if (type == RT_TEXTURED) {
+            if (COUNT) c.cn->c[CN_N_TEXFETCH]++;
+            col = texture_rgb(c.sc, h.u, h.v, h.tex);
+        }
+        scatter<COUNT>(c, r, out, h, type, extra, col, i + sample, gx, gy);
     }
     return out;
+}
+
+template <bool COUNT>
+PT_DEV V3 radiance(const Ctx &c, Ray r, uint32_t sample, uint32_t gx, uint32_t gy) {
+    return trace_from<COUNT>(c, r, mk(1.0f, 1.0f, 1.0f), 0, sample, gx, gy);
 }
 
 // :129-139, :500-505 — no pixel jitter
@@ -445,6 +502,82 @@ PT_DEV Ray primary_ray(const float *cam, uint32_t x, uint32_t y, int w, int h) {
     V3 llc = mk(cam[3], cam[4], cam[5]), hor = mk(cam[6], cam[7], cam[8]), ver = mk(cam[9], cam[10], cam[11]);
     r.d = normalize((llc + hor * s) + ver * t);
     return r;
+}
+
+// ---- shared deterministic prefix ---------------------------------------------------
+// The reference does not jitter the primary ray (:500-505), so all samples of a
+// pixel follow the SAME path until the first random event (a diffuse / textured /
+// dielectric surface).  That prefix is traced once per pixel (kernel pt_prefix)
+// and stored as a PixelRec; the per-sample kernel continues from it.  Bits are
+// unchanged: the same operations are merely not repeated per sample.
+struct PixelRec {        // 80 bytes
+    float4 p_kind;       // hit point, w = bits: kind (0 final colour, 1 stochastic vertex) | depth << 8 | type << 16
+    float4 n_extra;      // normal, material extra_data
+    float4 d;            // incoming ray direction
+    float4 out;          // path colour so far (kind 1) or the pixel's radiance for every sample (kind 0)
+    float4 col;          // material colour / texel
+};
+enum { REC_FINAL = 0, REC_VERTEX = 1 };
+
+template <bool COUNT>
+PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
+    PixelRec rec;
+    V3 out = mk(1.0f, 1.0f, 1.0f);
+    rec.p_kind = rec.n_extra = rec.d = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < RT_DEPTH; i++) {
+        Hit h;
+        if (!hit_scene<COUNT>(c, r, h)) {
+            out = mk(0.0f, 0.0f, 0.0f);
+            break;
+        }
+        if (COUNT) c.cn->c[CN_H_BOUNCE]++;
+        int type;
+        float extra;
+        V3 col;
+        load_material(c, h.mat, type, extra, col);
+        if (type == RT_LIGHT) {
+            out = vmin(out, col);
+            break;
+        }
+        if (type == RT_DIFFUSE || type == RT_TEXTURED || type == RT_DIELECTRIC) {
+            if (type == RT_TEXTURED) {
+                if (COUNT) c.cn->c[CN_N_TEXFETCH]++;
+                col = texture_rgb(c.sc, h.u, h.v, h.tex);
+            }
+            uint32_t bits = REC_VERTEX | (i << 8) | ((uint32_t)type << 16);
+            rec.p_kind = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(bits));
+            rec.n_extra = make_float4(h.n.x, h.n.y, h.n.z, extra);
+            rec.d = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+            rec.out = make_float4(out.x, out.y, out.z, 0.0f);
+            rec.col = make_float4(col.x, col.y, col.z, 0.0f);
+            return rec;
+        }
+        scatter<COUNT>(c, r, out, h, type, extra, col, 0, gx, gy);  // mirror / glass: no random numbers
+    }
+    rec.p_kind.w = __uint_as_float((uint32_t)REC_FINAL);
+    rec.out = make_float4(out.x, out.y, out.z, 0.0f);
+    return rec;
+}
+
+// radiance of one sample continuing from its pixel's record
+template <bool COUNT>
+PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, uint32_t gx, uint32_t gy) {
+    uint32_t bits = __float_as_uint(rec.p_kind.w);
+    if ((bits & 0xFFu) == REC_FINAL) return xyz(rec.out);
+    uint32_t depth = (bits >> 8) & 0xFFu;
+    int type = (int)(bits >> 16);
+    Ray r;
+    r.o = xyz(rec.p_kind);
+    r.d = xyz(rec.d);
+    Hit h;
+    h.p = xyz(rec.p_kind);
+    h.n = xyz(rec.n_extra);
+    h.u = h.v = 0.0f;
+    h.tex = 0;
+    h.mat = 0;
+    V3 out = xyz(rec.out);
+    scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), depth + sample, gx, gy);
+    return trace_from<COUNT>(c, r, out, depth + 1, sample, gx, gy);
 }
 
 }  // namespace pt

@@ -46,28 +46,62 @@ PT_DEV bool slot_to_pixel(const FrameParams &fp, uint32_t slot, uint32_t &x, uin
     return x < (uint32_t)fp.w && y < (uint32_t)fp.h;
 }
 
+// Counters are spread over COUNTER_REPLICAS rows (one per workgroup residue) so
+// that two million waves do not serialise on 14 addresses; the host sums the rows.
+#define COUNTER_REPLICAS 512
+#define COUNTER_STRIDE 16
 template <bool COUNT>
-PT_DEV void flush_counters(const LaneCounters &cn, unsigned long long *counters) {
+PT_DEV void flush_counters(const LaneCounters &cn, unsigned long long *counters, uint32_t scale) {
     if (!COUNT) return;
+    unsigned long long *row = counters + (size_t)(blockIdx.x % COUNTER_REPLICAS) * COUNTER_STRIDE;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
         uint32_t v = cn.c[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[i], (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&row[i], (unsigned long long)v * scale);
     }
 }
 
-// One work-item per (pixel, sample lane).  Lane l of a group of g = 2^group_log2
-// lanes traces samples first+l, first+l+g, ... of its pixel and sums them in
-// that order; the g partial sums are combined by an xor butterfly (a fixed
-// tree), and the group's lane 0 updates the pixel:
-//   MODE_ACCUM   accum += (sum, count)                      (rt_render_spp)
+PT_DEV void zero_counters(LaneCounters &cn) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) cn.c[i] = 0;
+}
+
+// xor-butterfly over the g lanes of a pixel group: a fixed summation tree
+PT_DEV V3 group_sum(V3 sum, uint32_t g) {
+    for (uint32_t off = g >> 1; off > 0; off >>= 1) {
+        sum.x += __shfl_xor(sum.x, off);
+        sum.y += __shfl_xor(sum.y, off);
+        sum.z += __shfl_xor(sum.z, off);
+    }
+    return sum;
+}
+
+PT_DEV void accumulate(float4 *__restrict__ accum, size_t pix, V3 sum, uint32_t count) {
+    float4 a = accum[pix];
+    a.x += sum.x;
+    a.y += sum.y;
+    a.z += sum.z;
+    a.w += (float)count;
+    accum[pix] = a;
+}
+
+// Direct path: one work-item per (pixel, sample lane), every sample traced from
+// the camera.  Lane l of a group of g = 2^group_log2 lanes traces samples
+// first+l, first+l+g, ... of its pixel and sums them in that order; the g partial
+// sums are combined by an xor butterfly, and the group's lane 0 updates the pixel:
+//   MODE_ACCUM   accum += (sum, count)                      (rt_render_spp, prefix sharing off)
 //   MODE_TRACE   image = sqrt(radiance(sample first))        (`trace`,  raytracer.cl:496-510)
 //   MODE_RETRACE image = sqrt(mix(new, image², k/(k+1)))     (`retrace`, raytracer.cl:512-532)
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp, float4 *__restrict__ accum,
                                                  float4 *__restrict__ image, unsigned long long *counters) {
+    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    LaneCounters cn;
+    if (COUNT) zero_counters(cn);
+    Ctx c{sc, stage_materials(sc, s_mat), &cn};
+
     uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t g = 1u << fp.group_log2;
     uint32_t slot = fp.slot_begin + (tid >> fp.group_log2);
@@ -75,33 +109,19 @@ __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp,
     uint32_t x = 0, y = 0;
     bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
 
-    LaneCounters cn;
-    if (COUNT)
-        for (int i = 0; i < 14; i++) cn.c[i] = 0;
-
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     if (valid) {
         Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
-            V3 c = radiance<COUNT>(sc, r0, s, x, y, &cn);
-            sum = sum + c;
+            sum = sum + radiance<COUNT>(c, r0, s, x, y);
         }
     }
-    for (uint32_t off = g >> 1; off > 0; off >>= 1) {
-        sum.x += __shfl_xor(sum.x, off);
-        sum.y += __shfl_xor(sum.y, off);
-        sum.z += __shfl_xor(sum.z, off);
-    }
+    sum = group_sum(sum, g);
     if (valid && lane == 0) {
         size_t pix = (size_t)y * fp.w + x;
         if (MODE == MODE_ACCUM) {
-            float4 a = accum[pix];
-            a.x += sum.x;
-            a.y += sum.y;
-            a.z += sum.z;
-            a.w += (float)fp.count;
-            accum[pix] = a;
+            accumulate(accum, pix, sum, fp.count);
         } else if (MODE == MODE_TRACE) {
             image[pix] = make_float4(sqrtf(sum.x), sqrtf(sum.y), sqrtf(sum.z), 1.0f);
         } else {
@@ -113,32 +133,273 @@ __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp,
             image[pix] = make_float4(sqrtf(o.x), sqrtf(o.y), sqrtf(o.z), 1.0f);
         }
     }
-    flush_counters<COUNT>(cn, counters);
+    flush_counters<COUNT>(cn, counters, 1);
+}
+
+// Fused path, stage 1: one work-item per owned PIXEL traces the sample-invariant
+// prefix of the pixel's paths (pt_device.hpp "shared deterministic prefix").
+// A pixel whose paths never meet a random event (sky, direct light, mirror /
+// glass chains) is finished here: all its samples are equal, and their sum in the
+// order of stage 2 (k sequential adds per lane, then log2(g) doublings) is
+// computed in closed form.  Other pixels are appended to the live list.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp, PixelRec *__restrict__ recs,
+                                                 uint32_t *__restrict__ live, uint32_t *__restrict__ live_count,
+                                                 float4 *__restrict__ accum, unsigned long long *counters) {
+    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    LaneCounters cn;
+    if (COUNT) zero_counters(cn);
+    Ctx c{sc, stage_materials(sc, s_mat), &cn};
+
+    uint32_t slot = fp.slot_begin + blockIdx.x * 256u + threadIdx.x;
+    uint32_t x = 0, y = 0;
+    bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
+    bool is_live = false;
+    if (valid) {
+        Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
+        PixelRec rec = trace_prefix<COUNT>(c, r0, x, y);
+        uint32_t g = 1u << fp.group_log2;
+        bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
+        if (final_px && (fp.count & (g - 1u)) == 0) {
+            V3 col = xyz(rec.out), sum = mk(0.0f, 0.0f, 0.0f);
+            for (uint32_t k = 0; k < (fp.count >> fp.group_log2); k++) sum = sum + col;
+            for (uint32_t off = g >> 1; off > 0; off >>= 1) sum = sum + sum;
+            accumulate(accum, (size_t)y * fp.w + x, sum, fp.count);
+            if (COUNT) cn.c[CN_SAMPLES] += 1;  // scaled by count below
+        } else {
+            recs[slot] = rec;
+            is_live = true;
+        }
+    }
+    // append live slots: one atomic per wave (order is irrelevant to the result)
+    unsigned long long m = __ballot(is_live);
+    if (m) {
+        uint32_t lane = threadIdx.x & 63u, n = (uint32_t)__popcll(m);
+        uint32_t base = 0;
+        if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(live_count, n);
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (is_live) live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+    }
+    flush_counters<COUNT>(cn, counters, fp.count);  // the prefix stands for `count` samples' worth of work
+}
+
+// Fused path, stage 2: one group of g lanes per LIVE pixel; each lane continues
+// its samples from the pixel's record.  Same summation order as pt_render.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+                                                  const uint32_t *__restrict__ live,
+                                                  const uint32_t *__restrict__ live_count,
+                                                  float4 *__restrict__ accum, unsigned long long *counters) {
+    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    LaneCounters cn;
+    if (COUNT) zero_counters(cn);
+    Ctx c{sc, stage_materials(sc, s_mat), &cn};
+
+    uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t g = 1u << fp.group_log2;
+    uint32_t li = tid >> fp.group_log2;
+    uint32_t lane = tid & (g - 1u);
+    uint32_t n_live = *live_count;
+    bool valid = li < n_live;
+    uint32_t x = 0, y = 0;
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    if (valid) {
+        uint32_t slot = live[li];
+        (void)slot_to_pixel(fp, slot, x, y);
+        PixelRec rec = recs[slot];
+        bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
+        for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
+            if (COUNT) cn.c[CN_SAMPLES]++;
+            sum = sum + radiance_from_rec<COUNT>(c, rec, s, x, y);
+        }
+        (void)final_px;
+    }
+    sum = group_sum(sum, g);
+    if (valid && lane == 0) accumulate(accum, (size_t)y * fp.w + x, sum, fp.count);
+    flush_counters<COUNT>(cn, counters, 1);
+}
+
+// Fused path, stage 2 with an in-wave SAMPLE QUEUE (default).  Path lengths differ
+// wildly between samples (1 bounce into the sky … 30 inside glass), so with one fixed
+// sample per lane most lanes of a wave idle while its longest path finishes.  Here a
+// wave owns P live pixels = up to QUEUE_SLOTS samples and its 64 lanes pull the next
+// sample whenever their path ends: every iteration is "scatter, then nearest hit" for
+// all lanes, new samples joining at the scatter step straight from their pixel's
+// record (staged in LDS).  A finished sample's radiance goes to its own LDS slot, and
+// the slots are summed in exactly the order of pt_render (lane l: samples l, l+g, …;
+// then the xor butterfly), so the result does not depend on which lane traced what.
+#define QUEUE_SLOTS 512
+#define QUEUE_MAX_PIXELS 16
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+                                                    const uint32_t *__restrict__ live,
+                                                    const uint32_t *__restrict__ live_count,
+                                                    float4 *__restrict__ accum, unsigned long long *counters,
+                                                    uint32_t pixels_per_wave) {
+    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    __shared__ float s_slot[4][QUEUE_SLOTS * 3];
+    __shared__ float4 s_rec[4][QUEUE_MAX_PIXELS * 5];
+    __shared__ uint32_t s_xy[4][QUEUE_MAX_PIXELS * 2];
+    LaneCounters cn;
+    if (COUNT) zero_counters(cn);
+    Ctx c{sc, stage_materials(sc, s_mat), &cn};
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_live = *live_count;
+    const uint32_t pix0 = (blockIdx.x * 4u + wave) * pixels_per_wave;
+    const uint32_t npix = pix0 < n_live ? min(pixels_per_wave, n_live - pix0) : 0u;
+    const uint32_t count = fp.count, total = npix * count;
+    float *slot = s_slot[wave];
+    const float4 *rec = s_rec[wave];
+    const uint32_t *xy = s_xy[wave];
+
+    // stage this wave's pixel records and coordinates
+    for (uint32_t i = lane; i < npix * 5u; i += 64u) {
+        uint32_t p = i / 5u, part = i - p * 5u;
+        s_rec[wave][i] = reinterpret_cast<const float4 *>(recs + live[pix0 + p])[part];
+    }
+    if (lane < npix) {
+        uint32_t x = 0, y = 0;
+        (void)slot_to_pixel(fp, live[pix0 + lane], x, y);
+        s_xy[wave][2 * lane] = x;
+        s_xy[wave][2 * lane + 1] = y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t next = 0;  // wave-uniform head of the queue
+    bool active = false;
+    uint32_t idx = 0, depth = 0, sample = 0, gx = 0, gy = 0;
+    int type = 0;
+    float extra = 0.0f;
+    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);
+    Ray r;
+    r.o = r.d = mk(0.0f, 0.0f, 0.0f);
+    Hit h;
+    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.tex = h.mat = 0;
+
+    while (true) {
+        // ---- refill idle lanes from the queue
+        bool need = !active;
+        unsigned long long m = __ballot(need);
+        if (m && next < total) {
+            uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (need && cand < total) {
+                idx = cand;
+                uint32_t p = 0;
+                for (uint32_t k = 1; k < npix; k++) p += (idx >= k * count) ? 1u : 0u;
+                sample = fp.first + (idx - p * count);
+                float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
+                       q4 = rec[5 * p + 4];
+                gx = xy[2 * p];
+                gy = xy[2 * p + 1];
+                uint32_t bits = __float_as_uint(q0.w);
+                if (COUNT) cn.c[CN_SAMPLES]++;
+                if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
+                    slot[3 * idx] = q3.x;
+                    slot[3 * idx + 1] = q3.y;
+                    slot[3 * idx + 2] = q3.z;
+                } else {
+                    depth = (bits >> 8) & 0xFFu;
+                    type = (int)(bits >> 16);
+                    h.p = xyz(q0);
+                    h.n = xyz(q1);
+                    extra = q1.w;
+                    r.o = xyz(q0);
+                    r.d = xyz(q2);
+                    out = xyz(q3);
+                    col = xyz(q4);
+                    active = true;
+                }
+            }
+            next += (uint32_t)__popcll(m);
+        }
+        if (!__any(active)) {
+            if (next >= total) break;
+            continue;  // every candidate was a final-colour pixel: keep draining the queue
+        }
+        // ---- one material interaction for every active lane
+        if (active) {
+            scatter<COUNT>(c, r, out, h, type, extra, col, depth + sample, gx, gy);
+            depth++;
+            if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
+                slot[3 * idx] = out.x;
+                slot[3 * idx + 1] = out.y;
+                slot[3 * idx + 2] = out.z;
+                active = false;
+            }
+        }
+        // ---- nearest hit for every lane still active
+        if (active) {
+            V3 res;
+            bool done = false;
+            if (!hit_scene<COUNT>(c, r, h)) {
+                res = mk(0.0f, 0.0f, 0.0f);
+                done = true;
+            } else {
+                if (COUNT) cn.c[CN_H_BOUNCE]++;
+                load_material(c, h.mat, type, extra, col);
+                if (type == RT_LIGHT) {
+                    res = vmin(out, col);
+                    done = true;
+                } else if (type == RT_TEXTURED) {
+                    if (COUNT) cn.c[CN_N_TEXFETCH]++;
+                    col = texture_rgb(c.sc, h.u, h.v, h.tex);
+                }
+            }
+            if (done) {
+                slot[3 * idx] = res.x;
+                slot[3 * idx + 1] = res.y;
+                slot[3 * idx + 2] = res.z;
+                active = false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- per-pixel sums in pt_render's order
+    const uint32_t g = 1u << fp.group_log2, ppp = 64u >> fp.group_log2;
+    for (uint32_t pb = 0; pb < npix; pb += ppp) {
+        uint32_t p = pb + (lane >> fp.group_log2), l = lane & (g - 1u);
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        if (p < npix)
+            for (uint32_t j = l; j < count; j += g) {
+                const float *sl = slot + 3u * (p * count + j);
+                sum = sum + mk(sl[0], sl[1], sl[2]);
+            }
+        sum = group_sum(sum, g);
+        if (p < npix && l == 0) accumulate(accum, (size_t)xy[2 * p + 1] * fp.w + xy[2 * p], sum, count);
+    }
+    flush_counters<COUNT>(cn, counters, 1);
 }
 
 // parity probe: one work-item per listed pixel-sample
 __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
                                                 const uint32_t *__restrict__ ys, const uint32_t *__restrict__ ss,
                                                 uint32_t n, float *__restrict__ out) {
+    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    Ctx c{sc, stage_materials(sc, s_mat), nullptr};
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
-    V3 c = radiance<false>(sc, r0, ss[i], xs[i], ys[i], nullptr);
-    out[3 * i] = c.x;
-    out[3 * i + 1] = c.y;
-    out[3 * i + 2] = c.z;
+    V3 col = radiance<false>(c, r0, ss[i], xs[i], ys[i]);
+    out[3 * i] = col.x;
+    out[3 * i + 1] = col.y;
+    out[3 * i + 2] = col.z;
 }
 
-// image = sqrt(accum / count), alpha 1; pixels this rank does not own stay 0
+// image = sqrt(accum.rgb / accum.w), alpha 1; pixels this rank does not own stay 0
 __global__ __launch_bounds__(256) void pt_resolve(const float4 *__restrict__ accum, float4 *__restrict__ image,
-                                                  uint32_t n, float count, int linear_only) {
+                                                  uint32_t n, int linear_only) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     float4 a = accum[i];
-    float cnt = count > 0.0f ? count : a.w;
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (cnt > 0.0f) {
-        float rx = a.x / cnt, ry = a.y / cnt, rz = a.z / cnt;
+    if (a.w > 0.0f) {
+        float rx = a.x / a.w, ry = a.y / a.w, rz = a.z / a.w;
         o = linear_only ? make_float4(rx, ry, rz, 1.0f) : make_float4(sqrtf(rx), sqrtf(ry), sqrtf(rz), 1.0f);
     }
     image[i] = o;
@@ -225,6 +486,8 @@ struct rt_context {
 
     DevBuf<rt_material> materials;
     DevBuf<rt_sphere> spheres;
+    DevBuf<float4> sph4;
+    uint32_t sphere_batches = 0;
     DevBuf<rt_plane> planes;
     DevBuf<rt_lens> lenses;
     DevBuf<rt_float3> vertices;
@@ -242,6 +505,11 @@ struct rt_context {
     float4 *d_image = nullptr;
     float4 *d_accum = nullptr;
     unsigned long long *d_counters = nullptr;
+    PixelRec *d_recs = nullptr;      // per owned pixel slot: shared path prefix (fused path)
+    uint32_t *d_live = nullptr;      // slots that need per-sample work + [capacity] = their count
+    size_t slot_capacity = 0;
+    bool prefix_sharing = true;
+    bool sample_queue = true;
     uint32_t accum_count = 0;
     uint32_t sample_counter = 0;
     bool count_enabled = false;
@@ -276,6 +544,11 @@ int alloc_frame(rt_context *ctx, int w, int h) {
     if (ctx->d_image) (void)hipFree(ctx->d_image);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     ctx->d_image = ctx->d_accum = nullptr;
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_live) (void)hipFree(ctx->d_live);
+    ctx->d_recs = nullptr;
+    ctx->d_live = nullptr;
+    ctx->slot_capacity = 0;
     size_t bytes = (size_t)w * h * sizeof(float4);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_image, bytes));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_accum, bytes));
@@ -292,6 +565,9 @@ DeviceScene device_scene(const rt_context *ctx) {
     DeviceScene s;
     s.materials = ctx->materials.p;
     s.spheres = ctx->spheres.p;
+    s.sph4 = ctx->sph4.p;
+    s.sphere_batches = ctx->sphere_batches;
+    s.material_count = (uint32_t)ctx->materials.n;
     s.planes = ctx->planes.p;
     s.lenses = ctx->lenses.p;
     s.vertices = ctx->vertices.p;
@@ -355,6 +631,21 @@ int check_ready(rt_context *ctx, const float *cam) {
     return RT_OK;
 }
 
+int ensure_slots(rt_context *ctx, size_t slots) {
+    if (slots <= ctx->slot_capacity) return RT_OK;
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_live) (void)hipFree(ctx->d_live);
+    ctx->d_recs = nullptr;
+    ctx->d_live = nullptr;
+    ctx->slot_capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_recs, slots * sizeof(PixelRec)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_live, (slots + 1) * sizeof(uint32_t)));
+    ctx->slot_capacity = slots;
+    return RT_OK;
+}
+
+// Direct path (every sample from the camera): trace / retrace compat modes, and the
+// fused mode when prefix sharing is switched off.
 template <int MODE>
 int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2) {
     FrameParams fp = frame_params(ctx, cam, first, count, glog2);
@@ -377,6 +668,56 @@ int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t
         else
             hipLaunchKernelGGL((pt_render<MODE, false>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum,
                                ctx->d_image, ctx->d_counters);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));
+    ctx->ev_count++;
+    return RT_OK;
+}
+
+// Fused path: pt_prefix (one work-item per pixel) + pt_samples (g lanes per live pixel).
+int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2) {
+    FrameParams fp = frame_params(ctx, cam, first, count, glog2);
+    DeviceScene sc = device_scene(ctx);
+    uint32_t slots = fp.slot_end;
+    if (slots == 0) return RT_OK;
+    int rc = ensure_slots(ctx, slots);
+    if (rc) return rc;
+    uint32_t *live_count = ctx->d_live + ctx->slot_capacity;
+    uint32_t slots_per_launch = ctx->max_threads_per_launch >> glog2;
+    if (slots_per_launch == 0) slots_per_launch = 1;
+    hipEvent_t *evp = ctx->ev[ctx->ev_count % rt_context::EV_RING];
+    HIP_TRY(ctx, hipEventRecord(evp[0], ctx->stream));
+    for (uint32_t b = 0; b < slots; b += slots_per_launch) {
+        fp.slot_begin = b;
+        fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
+        uint32_t n = fp.slot_end - fp.slot_begin;
+        HIP_TRY(ctx, hipMemsetAsync(live_count, 0, sizeof(uint32_t), ctx->stream));
+        dim3 block(256), grid1((n + 255) / 256), grid2((unsigned)((((uint64_t)n << glog2) + 255) / 256));
+        // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
+        uint32_t ppw = QUEUE_SLOTS / count;
+        ppw = ppw < 1 ? 1 : (ppw > QUEUE_MAX_PIXELS ? QUEUE_MAX_PIXELS : ppw);
+        dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
+        bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
+        if (ctx->count_enabled) {
+            hipLaunchKernelGGL((pt_prefix<true>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                               live_count, ctx->d_accum, ctx->d_counters);
+            if (queue)
+                hipLaunchKernelGGL((pt_samples_q<true>), gridq, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                                   live_count, ctx->d_accum, ctx->d_counters, ppw);
+            else
+                hipLaunchKernelGGL((pt_samples<true>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                                   live_count, ctx->d_accum, ctx->d_counters);
+        } else {
+            hipLaunchKernelGGL((pt_prefix<false>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                               live_count, ctx->d_accum, ctx->d_counters);
+            if (queue)
+                hipLaunchKernelGGL((pt_samples_q<false>), gridq, block, 0, ctx->stream, sc, fp, ctx->d_recs,
+                                   ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw);
+            else
+                hipLaunchKernelGGL((pt_samples<false>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                                   live_count, ctx->d_accum, ctx->d_counters);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));
@@ -444,8 +785,8 @@ int rt_create(int device, int width, int height, rt_context **out) {
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < rt_context::EV_RING; i++)
         if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
-    if (hipMalloc((void **)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
+    if (hipMalloc((void **)&ctx->d_counters, COUNTER_REPLICAS * COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, COUNTER_REPLICAS * COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
     if ((rc = rt_set_seed(ctx, 0xC0FFEEull)) != RT_OK) return bail(rc);
     if ((rc = rt_set_textures(ctx, nullptr, 0, 0, 0)) != RT_OK) return bail(rc);
@@ -463,6 +804,9 @@ void rt_destroy(rt_context *ctx) {
     if (ctx->d_image) (void)hipFree(ctx->d_image);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_live) (void)hipFree(ctx->d_live);
+    ctx->sph4.release();
     for (int i = 0; i < rt_context::EV_RING; i++)
         for (int k = 0; k < 2; k++)
             if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
@@ -539,6 +883,18 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
     ctx->have_scene = false;
     HIP_TRY(ctx, ctx->materials.upload(d->materials, d->material_count));
     HIP_TRY(ctx, ctx->spheres.upload(d->spheres, d->sphere_count));
+    {
+        // test layout of the spheres: (cx, cy, cz, r*r), whole batches, then one dummy batch that the
+        // prefetch of the last iteration reads.  Dummies have r*r = -inf: their discriminant is -inf.
+        uint32_t batches = (d->sphere_count + PT_SPHERE_BATCH - 1) / PT_SPHERE_BATCH;
+        std::vector<float4> v((size_t)(batches + 1) * PT_SPHERE_BATCH, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
+        for (uint32_t i = 0; i < d->sphere_count; i++) {
+            volatile float r2 = d->spheres[i].r * d->spheres[i].r;  // one rounded binary32 product, as in hitSphere
+            v[i] = make_float4(d->spheres[i].pos.x, d->spheres[i].pos.y, d->spheres[i].pos.z, r2);
+        }
+        HIP_TRY(ctx, ctx->sph4.upload(v.data(), v.size()));
+        ctx->sphere_batches = batches;
+    }
     HIP_TRY(ctx, ctx->planes.upload(d->planes, d->plane_count));
     HIP_TRY(ctx, ctx->lenses.upload(d->lenses, d->lens_count));
     HIP_TRY(ctx, ctx->vertices.upload(d->vertices, d->vertex_count));
@@ -659,14 +1015,16 @@ int rt_render_spp(rt_context *ctx, const float camera[12], uint32_t first_sample
     if ((uint64_t)first_sample + n_samples - 1 > RT_MAX_SAMPLE)
         return fail(ctx, RT_EINVAL, "samples %u..+%u exceed the limit %u", first_sample, n_samples, RT_MAX_SAMPLE);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((rc = launch_render<MODE_ACCUM>(ctx, camera, first_sample, n_samples, group_log2_for(n_samples))) != RT_OK) return rc;
+    rc = ctx->prefix_sharing ? launch_fused(ctx, camera, first_sample, n_samples, group_log2_for(n_samples))
+                             : launch_render<MODE_ACCUM>(ctx, camera, first_sample, n_samples, group_log2_for(n_samples));
+    if (rc != RT_OK) return rc;
     ctx->accum_count += n_samples;
     return RT_OK;
 }
 
 static int resolve_into(rt_context *ctx, int linear_only) {
     uint32_t n = (uint32_t)ctx->width * ctx->height;
-    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_image, n, 0.0f,
+    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_image, n,
                        linear_only);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -734,7 +1092,7 @@ int rt_read_linear(rt_context *ctx, float *rgba, size_t bytes) {
     float4 *tmp = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&tmp, need));
     uint32_t n = (uint32_t)ctx->width * ctx->height;
-    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, tmp, n, 0.0f, 1);
+    hipLaunchKernelGGL(pt_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_accum, tmp, n, 1);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(rgba, tmp, need, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -761,21 +1119,37 @@ int rt_enable_counters(rt_context *ctx, int enable) {
     return RT_OK;
 }
 
+int rt_set_option(rt_context *ctx, int option, int value) {
+    if (!ctx) return RT_EINVAL;
+    switch (option) {
+        case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
+        case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
+        case RT_OPT_MAX_THREADS_PER_LAUNCH:
+            if (value < 256) return fail(ctx, RT_EINVAL, "max threads per launch must be >= 256");
+            ctx->max_threads_per_launch = (uint32_t)value;
+            return RT_OK;
+        default: return fail(ctx, RT_EINVAL, "unknown option %d", option);
+    }
+}
+
 int rt_reset_counters(rt_context *ctx) {
     if (!ctx) return RT_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, COUNTER_REPLICAS * COUNTER_STRIDE * sizeof(unsigned long long), ctx->stream));
     return RT_OK;
 }
 
 int rt_get_counters(rt_context *ctx, rt_counters *out) {
     if (!ctx || !out) return RT_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    unsigned long long h[16];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h(COUNTER_REPLICAS * COUNTER_STRIDE);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t *o = (uint64_t *)out;
-    for (int i = 0; i < 14; i++) o[i] = h[i];
+    for (int i = 0; i < 14; i++) {
+        o[i] = 0;
+        for (int r = 0; r < COUNTER_REPLICAS; r++) o[i] += h[(size_t)r * COUNTER_STRIDE + i];
+    }
     return RT_OK;
 }
 

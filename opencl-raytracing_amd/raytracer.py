@@ -26,7 +26,7 @@ SYMBOLS = (
     "rt_set_shard", "rt_render", "rt_render_again", "rt_sample_counter", "rt_clear", "rt_render_spp", "rt_resolve",
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
-    "rt_kernel_ms_history", "rt_device_info",
+    "rt_kernel_ms_history", "rt_device_info", "rt_set_option",
 )
 
 
@@ -85,6 +85,7 @@ def load_library(path=LIB_PATH):
     lib.rt_counters_bytes.restype = u64
     lib.rt_last_kernel_ms.argtypes = [vp, fp]
     lib.rt_kernel_ms_history.argtypes = [vp, fp, sz, C.POINTER(sz)]
+    lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.c_char_p, sz]
     if lib.rt_abi_version() != _abi.RT_ABI_VERSION:
         raise OSError("librt_amd.so ABI %d != expected %d" % (lib.rt_abi_version(), _abi.RT_ABI_VERSION))
@@ -186,6 +187,11 @@ class RayTracer:
 
     def setShard(self, rank, world, tile_w=8, tile_h=8):
         self._check(self._lib.rt_set_shard(self._ctx, rank, world, tile_w, tile_h))
+
+    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE = 1, 2, 3
+
+    def setOption(self, option, value):
+        self._check(self._lib.rt_set_option(self._ctx, option, int(value)))
 
     def setStream(self, hip_stream):
         self._check(self._lib.rt_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))

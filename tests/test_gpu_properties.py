@@ -146,3 +146,31 @@ def test_error_behaviour():
     cam = (C.c_float * 12)()
     assert lib.rt_render(ctx, cam) == -4 and b"no scene" in lib.rt_last_error(ctx)
     lib.rt_destroy(ctx)
+
+
+@pytest.mark.parametrize("name,kw,spps", [
+    ("all_kinds", dict(width=160, height=96), (1, 3, 64, 100, 128)),
+    ("c2", dict(width=320, height=180), (64,)),
+    ("c3", dict(width=160, height=90, tex_size=64), (16, 256)),
+])
+def test_prefix_sharing_and_sample_queue_change_no_bit(name, kw, spps):
+    """The fused path (shared per-pixel prefix, in-wave sample queue) against the same path
+    without the queue and against the direct path that traces every sample from the camera:
+    identical accumulators and counters."""
+    wl = rt.workloads.get(name, **kw)
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    for spp in spps:
+        out = []
+        for share, queue in ((1, 1), (1, 0), (0, 0)):
+            t.setOption(t.OPT_PREFIX_SHARING, share)
+            t.setOption(t.OPT_SAMPLE_QUEUE, queue)
+            t.enableCounters(True)
+            t.resetCounters()
+            t.clear()
+            t.renderSamples(wl.camera, 5, spp)
+            out.append((t.readLinear(), t.counters().as_dict()))
+            t.enableCounters(False)
+        for o in out[1:]:
+            assert np.array_equal(out[0][0].view(np.uint32), o[0].view(np.uint32)), spp
+            assert out[0][1] == o[1], spp
+    t.close()
