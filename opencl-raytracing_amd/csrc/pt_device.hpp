@@ -60,6 +60,14 @@ struct Ray {
 };
 PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 
+// tuning switches (A/B-tested on MI355X; results never depend on them)
+#ifndef PT_RNG_PREFETCH
+#define PT_RNG_PREFETCH 0  // issue the table gathers before the nearest-hit search
+#endif
+#ifndef PT_BEHIND_SKIP
+#define PT_BEHIND_SKIP 1   // skip the square root for spheres behind the ray origin
+#endif
+
 #define PT_LDS_MATERIALS 64  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
 #define PT_SPHERE_BATCH 4
 
@@ -134,14 +142,23 @@ PT_DEV uint32_t dir_hash(V3 d) {
     float dp = dot(d, mk(123.9898f, 348.233f, 433.3314f));
     return (uint32_t)fabs((double)dp * 438.5453);
 }
-PT_DEV V3 random_vec(const float *__restrict__ table, V3 dir, uint32_t s_seed, uint32_t gx, uint32_t gy) {
-    uint32_t idx = (dir_hash(dir) + (s_seed * 2683u + gx * 3931u + gy * 2504u) * 3u) % RT_RANDOM_BUFFER_SIZE;
-    const float *t = table + idx;  // three consecutive FLOATS at float offset idx (:109-111,117)
-    return mk(t[0], t[1], t[2]);
-}
-PT_DEV float random_u(const float *__restrict__ table, V3 dir, uint32_t s_seed, uint32_t gx, uint32_t gy) {
-    uint32_t idx = (dir_hash(dir) + (s_seed * 2683u + gx * 3931u + gy)) % RT_RANDOM_BUFFER_SIZE;
-    return table[3 * RT_RANDOM_BUFFER_SIZE + idx];
+// Both table reads of a bounce depend only on the INCOMING direction and the
+// seed, so they are issued before the nearest-hit search and consumed after it
+// (the gather latency hides behind the intersection arithmetic).  randomVec (:113)
+// feeds t_diffuse / t_textured, random (:120) feeds t_dielectric.
+struct Rnd {
+    V3 v;     // three consecutive FLOATS at float offset idx (:109-111,117)
+    float u;
+};
+PT_DEV Rnd fetch_rnd(const float *__restrict__ table, V3 dir, uint32_t s_seed, uint32_t gx, uint32_t gy) {
+    uint32_t hsh = dir_hash(dir);
+    uint32_t iv = (hsh + (s_seed * 2683u + gx * 3931u + gy * 2504u) * 3u) % RT_RANDOM_BUFFER_SIZE;
+    uint32_t iu = (hsh + (s_seed * 2683u + gx * 3931u + gy)) % RT_RANDOM_BUFFER_SIZE;
+    const float *t = table + iv;
+    Rnd r;
+    r.v = mk(t[0], t[1], t[2]);
+    r.u = table[3 * RT_RANDOM_BUFFER_SIZE + iu];
+    return r;
 }
 
 // ---- nearest-hit search --------------------------------------------------------
@@ -157,7 +174,10 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float cc = dot(oc, oc) - s.w;
     float dis = b * b - cc;
     float t = -1.0f;
-    if (dis > 0) {
+    // Centre behind the origin (b < 0) and origin outside the sphere (cc > 0): the far root is
+    // b + sqrt(b*b - cc) <= |b|·2^-23 < MIN_DISTANCE for |b| < 4096, the near root is negative —
+    // the reference rejects both, so the square root is skipped.  Exact, not an approximation.
+    if (dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > -4096.0f)) {
         float d = sqrtf(dis);
         float t0 = b - d;
         if (in_range(t0)) t = t0;
@@ -417,14 +437,12 @@ PT_DEV V3 texture_rgb(const DeviceScene &sc, float s, float t, uint32_t tex_id) 
 // direction = v, normalised unless it is a refraction (:386,:428 do not
 // renormalise).
 template <bool COUNT>
-PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, uint32_t seed,
-                    uint32_t gx, uint32_t gy) {
+PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, const Rnd &rnd) {
     V3 v;
     bool renorm = true;
     if (type == RT_DIFFUSE || type == RT_TEXTURED) {
         if (COUNT) c.cn->c[CN_N_SCATTER]++;
-        V3 rv = random_vec(c.sc.table, r.d, seed, gx, gy);
-        v = h.n + rv;
+        v = h.n + rnd.v;
         out = out * extra;
     } else if (type == RT_REFLECTIVE) {
         float k = 2.0f * dot(r.d, h.n);
@@ -446,8 +464,7 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
         if (type == RT_DIELECTRIC) {
             if (COUNT) c.cn->c[CN_N_DIELECTRIC]++;
             float prob = schlick(-cai, ratio);
-            float rnd = random_u(c.sc.table, r.d, seed, gx, gy);
-            want = prob < rnd;
+            want = prob < rnd.u;
         }
         float disc = 1.0f - ratio * ratio * (1.0f - cai * cai);
         if (want && disc > 0.0f) {
@@ -471,6 +488,7 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
 template <bool COUNT>
 PT_DEV V3 trace_from(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t sample, uint32_t gx, uint32_t gy) {
     for (uint32_t i = i0; i < RT_DEPTH; i++) {
+        Rnd rnd = fetch_rnd(c.sc.table, r.d, i + sample, gx, gy);
         Hit h;
         if (!hit_scene<COUNT>(c, r, h)) return mk(0.0f, 0.0f, 0.0f);
         if (COUNT) c.cn->c[CN_H_BOUNCE]++;
@@ -483,7 +501,7 @@ PT_DEV V3 trace_from(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t sample, 
             if (COUNT) c.cn->c[CN_N_TEXFETCH]++;
             col = texture_rgb(c.sc, h.u, h.v, h.tex);
         }
-        scatter<COUNT>(c, r, out, h, type, extra, col, i + sample, gx, gy);
+        scatter<COUNT>(c, r, out, h, type, extra, col, rnd);
     }
     return out;
 }
@@ -552,7 +570,10 @@ PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
             rec.col = make_float4(col.x, col.y, col.z, 0.0f);
             return rec;
         }
-        scatter<COUNT>(c, r, out, h, type, extra, col, 0, gx, gy);  // mirror / glass: no random numbers
+        Rnd none;  // mirror / glass: no random numbers
+        none.v = mk(0.0f, 0.0f, 0.0f);
+        none.u = 0.0f;
+        scatter<COUNT>(c, r, out, h, type, extra, col, none);
     }
     rec.p_kind.w = __uint_as_float((uint32_t)REC_FINAL);
     rec.out = make_float4(out.x, out.y, out.z, 0.0f);
@@ -576,7 +597,8 @@ PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, 
     h.tex = 0;
     h.mat = 0;
     V3 out = xyz(rec.out);
-    scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), depth + sample, gx, gy);
+    Rnd rnd = fetch_rnd(c.sc.table, r.d, depth + sample, gx, gy);
+    scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), rnd);
     return trace_from<COUNT>(c, r, out, depth + 1, sample, gx, gy);
 }
 

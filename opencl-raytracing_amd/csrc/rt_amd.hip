@@ -228,41 +228,56 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
 // record (staged in LDS).  A finished sample's radiance goes to its own LDS slot, and
 // the slots are summed in exactly the order of pt_render (lane l: samples l, l+g, …;
 // then the xor butterfly), so the result does not depend on which lane traced what.
-#define QUEUE_SLOTS 512
+#ifndef QUEUE_SLOTS
+#define QUEUE_SLOTS 512   // upper bound of samples a wave owns; the launch picks pixels_per_wave
+#endif
+#ifndef QUEUE_TARGET
+#define QUEUE_TARGET 512  // samples per wave aimed for (A/B on MI355X: 256 and 512 tie at 64 spp, 512 wins at 256 spp)
+#endif
 #define QUEUE_MAX_PIXELS 16
+// dynamic LDS of pt_samples_q, per workgroup: materials, then per wave {records, coordinates, slots}
+__host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wave, uint32_t count) {
+    uint32_t b = pixels_per_wave * 5u * 16u + pixels_per_wave * 2u * 4u + pixels_per_wave * count * 3u * 4u;
+    return (b + 15u) & ~15u;
+}
+#ifndef PT_Q_WAVES
+#define PT_Q_WAVES 5  // waves per SIMD the register allocator must leave room for (A/B: 4 → 3.15 ms, 5 → 2.91, 6 → 3.39)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+__global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, unsigned long long *counters,
                                                     uint32_t pixels_per_wave) {
-    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
-    __shared__ float s_slot[4][QUEUE_SLOTS * 3];
-    __shared__ float4 s_rec[4][QUEUE_MAX_PIXELS * 5];
-    __shared__ uint32_t s_xy[4][QUEUE_MAX_PIXELS * 2];
+    extern __shared__ float4 s_dyn[];  // 16-byte aligned: no static LDS in this kernel
+    float4 *s_mat = s_dyn;
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    char *wave_lds = reinterpret_cast<char *>(s_dyn + 2 * PT_LDS_MATERIALS) +
+                     (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
+    float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
+    uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
+    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
     const uint32_t n_live = *live_count;
     const uint32_t pix0 = (blockIdx.x * 4u + wave) * pixels_per_wave;
     const uint32_t npix = pix0 < n_live ? min(pixels_per_wave, n_live - pix0) : 0u;
     const uint32_t count = fp.count, total = npix * count;
-    float *slot = s_slot[wave];
-    const float4 *rec = s_rec[wave];
-    const uint32_t *xy = s_xy[wave];
+    const float4 *rec = s_rec;
+    const uint32_t *xy = s_xy;
 
     // stage this wave's pixel records and coordinates
     for (uint32_t i = lane; i < npix * 5u; i += 64u) {
         uint32_t p = i / 5u, part = i - p * 5u;
-        s_rec[wave][i] = reinterpret_cast<const float4 *>(recs + live[pix0 + p])[part];
+        s_rec[i] = reinterpret_cast<const float4 *>(recs + live[pix0 + p])[part];
     }
     if (lane < npix) {
         uint32_t x = 0, y = 0;
         (void)slot_to_pixel(fp, live[pix0 + lane], x, y);
-        s_xy[wave][2 * lane] = x;
-        s_xy[wave][2 * lane + 1] = y;
+        s_xy[2 * lane] = x;
+        s_xy[2 * lane + 1] = y;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -279,6 +294,9 @@ __global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams 
     h.p = h.n = mk(0.0f, 0.0f, 0.0f);
     h.u = h.v = 0.0f;
     h.tex = h.mat = 0;
+    Rnd rnd;
+    rnd.v = mk(0.0f, 0.0f, 0.0f);
+    rnd.u = 0.0f;
 
     while (true) {
         // ---- refill idle lanes from the queue
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams 
                     r.d = xyz(q2);
                     out = xyz(q3);
                     col = xyz(q4);
+                    if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
                     active = true;
                 }
             }
@@ -322,7 +341,8 @@ __global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams 
         }
         // ---- one material interaction for every active lane
         if (active) {
-            scatter<COUNT>(c, r, out, h, type, extra, col, depth + sample, gx, gy);
+            if (!PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+            scatter<COUNT>(c, r, out, h, type, extra, col, rnd);
             depth++;
             if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
                 slot[3 * idx] = out.x;
@@ -331,8 +351,10 @@ __global__ __launch_bounds__(256) void pt_samples_q(DeviceScene sc, FrameParams 
                 active = false;
             }
         }
-        // ---- nearest hit for every lane still active
+        // ---- nearest hit for every lane still active; the table reads of the NEXT material
+        // interaction are issued first (they depend on the ray direction only)
         if (active) {
+            if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
             V3 res;
             bool done = false;
             if (!hit_scene<COUNT>(c, r, h)) {
@@ -695,15 +717,16 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         HIP_TRY(ctx, hipMemsetAsync(live_count, 0, sizeof(uint32_t), ctx->stream));
         dim3 block(256), grid1((n + 255) / 256), grid2((unsigned)((((uint64_t)n << glog2) + 255) / 256));
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
-        uint32_t ppw = QUEUE_SLOTS / count;
+        uint32_t ppw = QUEUE_TARGET / count;
         ppw = ppw < 1 ? 1 : (ppw > QUEUE_MAX_PIXELS ? QUEUE_MAX_PIXELS : ppw);
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
+        size_t lds_q = 2 * PT_LDS_MATERIALS * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
         if (ctx->count_enabled) {
             hipLaunchKernelGGL((pt_prefix<true>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
                                live_count, ctx->d_accum, ctx->d_counters);
             if (queue)
-                hipLaunchKernelGGL((pt_samples_q<true>), gridq, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
+                hipLaunchKernelGGL((pt_samples_q<true>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
                                    live_count, ctx->d_accum, ctx->d_counters, ppw);
             else
                 hipLaunchKernelGGL((pt_samples<true>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
@@ -712,7 +735,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
             hipLaunchKernelGGL((pt_prefix<false>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
                                live_count, ctx->d_accum, ctx->d_counters);
             if (queue)
-                hipLaunchKernelGGL((pt_samples_q<false>), gridq, block, 0, ctx->stream, sc, fp, ctx->d_recs,
+                hipLaunchKernelGGL((pt_samples_q<false>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs,
                                    ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw);
             else
                 hipLaunchKernelGGL((pt_samples<false>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,

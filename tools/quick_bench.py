@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import opencl_raytracing_amd as rt
 
-for spec in sys.argv[1:]:
+args = sys.argv[1:]
+if args and args[0].startswith("--lib="):
+    rt.load_library(args.pop(0)[6:])
+for spec in args:
     parts = spec.split(":")
     name, spp = parts[0], int(parts[1])
     kw = {}
