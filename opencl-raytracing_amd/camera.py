@@ -7,11 +7,32 @@ All arithmetic is float32 in the reference's order; ``tan/sin/cos`` come from th
 host libm (as in the reference), so the block is reproducible per host, and the
 kernels' parity is pinned on the block, not on libm.
 """
+import ctypes
+import ctypes.util
 import math
 
 import numpy as np
 
 f32 = np.float32
+
+# the reference calls cos/sin/tan on floats (glm::cos(float) → cosf): use the host libm's
+# single-precision functions, as its C++ does, rather than rounding double results
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+for _n in ("cosf", "sinf", "tanf"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float]
+
+
+def cosf(x):
+    return f32(_libm.cosf(float(f32(x))))
+
+
+def sinf(x):
+    return f32(_libm.sinf(float(f32(x))))
+
+
+def tanf(x):
+    return f32(_libm.tanf(float(f32(x))))
 
 FORWARD, BACK, LEFT, RIGHT = range(4)  # enum CameraMovementDirection, camera.h:13-18
 
@@ -42,15 +63,14 @@ class Camera:
         self.yaw, self.pitch = f32(y), f32(p)
         self.speed = CAMERA_SPEED_SLOW
         angle = f32(float(self.fov) * math.pi / 180.0)  # double arithmetic, camera.cpp:47
-        self.half_height = f32(math.tan(f32(angle * f32(0.5))))
+        self.half_height = tanf(angle * f32(0.5))
         self.half_width = self.aspect * self.half_height
         self._updateVectors()
 
     def _updateVectors(self):  # camera.cpp:26-37
         rp = self.pitch * f32(0.01745329251994329576923690768489)
         ry = self.yaw * f32(0.01745329251994329576923690768489)
-        w = np.array([f32(math.cos(rp)) * f32(math.sin(ry)), f32(math.sin(rp)), f32(math.cos(rp)) * f32(math.cos(ry))],
-                     dtype=f32)
+        w = np.array([cosf(rp) * sinf(ry), sinf(rp), cosf(rp) * cosf(ry)], dtype=f32)
         self.w = _norm(w)
         self.u = _norm(_cross(self.w, UP_DIR))
         self.v = _cross(self.u, self.w)
@@ -60,7 +80,7 @@ class Camera:
 
     def _setFov(self):  # camera.cpp:39-44 (uses the 0.0055556f approximation of 1/180)
         angle = f32(float(self.fov) * math.pi * float(f32(0.0055556)))
-        self.half_height = f32(math.tan(f32(angle * f32(0.5))))
+        self.half_height = tanf(angle * f32(0.5))
         self.half_width = self.aspect * self.half_height
         self._updateVectors()
 

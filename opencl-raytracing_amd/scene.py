@@ -52,8 +52,9 @@ def _scale(m, v):
 
 
 def _rotate(m, angle, axis):
+    from .camera import cosf, sinf  # libm's single-precision functions, as glm::rotate<float> uses
     a = f32(angle)
-    c, s = f32(math.cos(a)), f32(math.sin(a))
+    c, s = cosf(a), sinf(a)
     ax = np.asarray(axis, dtype=f32)
     ax = ax / f32(np.sqrt(f32(np.dot(ax, ax))))
     t = (f32(1) - c) * ax
@@ -435,7 +436,7 @@ def _read_obj(path):
                         cur["has_uv"] = False
                         cur["uv"].append([0.0, 0.0])
                     else:
-                        cur["uv"].append([vt[ti][0], 1.0 - vt[ti][1]])
+                        cur["uv"].append([f32(vt[ti][0]), f32(1.0) - f32(vt[ti][1])])  # FlipUVs, in float
                 for k in range(1, len(corners) - 1):
                     cur["idx"] += [b, b + k, b + k + 1]
     flush()
