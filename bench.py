@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
+                    help="N>1: gather of packed tiles (default) or full-frame RCCL reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg")
     args = ap.parse_args()
@@ -125,7 +127,7 @@ def main():
     base_spp = args.spp or wl.spp
     spp = base_spp * world                       # weak scaling: per-GPU pixel-samples fixed
     tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=local, seed=rt.workloads.SEED)
-    renderer = dist_mod.ShardedRenderer(tracer, rank, world)
+    renderer = dist_mod.ShardedRenderer(dist_mod.GpuShard(tracer, rank, world), rank, world, exchange=args.exchange)
     table = tracer.getRandomTable() if rank == 0 else None
 
     def step():
@@ -184,11 +186,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_DESC[args.workload], "width": wl.width, "height": wl.height,
                        "spp_per_gpu": base_spp, "spp_total": spp, "sharding": "8x8 tiles interleaved over %d rank(s)"
-                       % world + ("; RCCL reduce of the radiance buffer to rank 0" if world > 1 else ""),
+                       % world + ("; RCCL %s of the radiance buffer to rank 0" % args.exchange if world > 1 else ""),
                        "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "pt_render<MODE_ACCUM>", "kernel_ms": round(launch_ms, 4),
+                         "kernel": "pt_prefix + pt_samples_q (one fused trace call)", "kernel_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_pixel_sample": round(alg_bytes / max(my_samples, 1), 1),
                          "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3)},

@@ -242,6 +242,16 @@ int rt_make_random_table(uint64_t seed, float *out, size_t n);
  */
 int rt_set_shard(rt_context *ctx, int rank, int world, int tile_w, int tile_h);
 
+/* Compact exchange of a sharded accumulator (new).  rt_shard_slots: number of pixel
+ * slots every rank of `world` packs (whole tiles, the same for all ranks).
+ * rt_pack_accum: this rank's owned accumulator pixels → d_packed (device, slots × 16 B,
+ * slot order).  rt_unpack_accum: scatter the packed pixels of rank `src_rank` of
+ * `world` into this context's accumulator.  gather(packed) + unpack on rank 0 moves
+ * 1/world of the frame per rank over xGMI instead of a full-frame reduce. */
+int rt_shard_slots(rt_context *ctx, int world, uint32_t *slots_out);
+int rt_pack_accum(rt_context *ctx, void *d_packed, size_t bytes);
+int rt_unpack_accum(rt_context *ctx, const void *d_packed, size_t bytes, int src_rank, int world);
+
 /* ---- rendering ----------------------------------------------------------- */
 
 /* Replaces RayTracer::render (src/raytracer.cpp:127-144) + kernel `trace`

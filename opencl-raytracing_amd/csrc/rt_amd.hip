@@ -413,6 +413,25 @@ __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, 
     out[3 * i + 2] = col.z;
 }
 
+// Multi-GPU exchange: the accumulator pixels a rank owns, packed in slot order (what
+// travels over xGMI is 1/world of the frame instead of the whole frame) ...
+__global__ __launch_bounds__(256) void pt_pack(FrameParams fp, const float4 *__restrict__ accum,
+                                               float4 *__restrict__ packed, uint32_t n_slots) {
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n_slots) return;
+    uint32_t x, y;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (slot < fp.slot_end && slot_to_pixel(fp, slot, x, y)) v = accum[(size_t)y * fp.w + x];
+    packed[slot] = v;
+}
+// ... and the inverse on the receiving rank: fp describes the SENDER's shard
+__global__ __launch_bounds__(256) void pt_unpack(FrameParams fp, const float4 *__restrict__ packed,
+                                                 float4 *__restrict__ accum) {
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    uint32_t x, y;
+    if (slot < fp.slot_end && slot_to_pixel(fp, slot, x, y)) accum[(size_t)y * fp.w + x] = packed[slot];
+}
+
 // image = sqrt(accum.rgb / accum.w), alpha 1; pixels this rank does not own stay 0
 __global__ __launch_bounds__(256) void pt_resolve(const float4 *__restrict__ accum, float4 *__restrict__ image,
                                                   uint32_t n, int linear_only) {
@@ -1139,6 +1158,47 @@ int rt_device_accum(rt_context *ctx, void **d_rgba) {
 int rt_enable_counters(rt_context *ctx, int enable) {
     if (!ctx) return RT_EINVAL;
     ctx->count_enabled = enable != 0;
+    return RT_OK;
+}
+
+int rt_shard_slots(rt_context *ctx, int world, uint32_t *slots_out) {
+    if (!ctx || !slots_out || world < 1) return RT_EINVAL;
+    uint32_t tw = 1u << ctx->tile_w_log2, th = 1u << ctx->tile_h_log2;
+    uint32_t tiles = ((ctx->width + tw - 1) / tw) * ((ctx->height + th - 1) / th);
+    *slots_out = ((tiles + world - 1) / world) * tw * th;  // the same for every rank of `world`
+    return RT_OK;
+}
+
+int rt_pack_accum(rt_context *ctx, void *d_packed, size_t bytes) {
+    if (!ctx || !d_packed) return RT_EINVAL;
+    uint32_t n = 0;
+    rt_shard_slots(ctx, ctx->world, &n);
+    if (bytes != (size_t)n * sizeof(float4)) return fail(ctx, RT_EINVAL, "packed buffer must be %zu bytes", (size_t)n * sizeof(float4));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float cam0[12] = {0};
+    FrameParams fp = frame_params(ctx, cam0, 0, 0, 0);
+    hipLaunchKernelGGL(pt_pack, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fp, ctx->d_accum, (float4 *)d_packed, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_unpack_accum(rt_context *ctx, const void *d_packed, size_t bytes, int src_rank, int world) {
+    if (!ctx || !d_packed) return RT_EINVAL;
+    if (world < 1 || src_rank < 0 || src_rank >= world) return fail(ctx, RT_EINVAL, "rank %d of %d", src_rank, world);
+    uint32_t n = 0;
+    rt_shard_slots(ctx, world, &n);
+    if (bytes != (size_t)n * sizeof(float4)) return fail(ctx, RT_EINVAL, "packed buffer must be %zu bytes", (size_t)n * sizeof(float4));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int keep_rank = ctx->rank, keep_world = ctx->world;
+    ctx->rank = src_rank;
+    ctx->world = world;
+    float cam0[12] = {0};
+    FrameParams fp = frame_params(ctx, cam0, 0, 0, 0);
+    ctx->rank = keep_rank;
+    ctx->world = keep_world;
+    if (fp.slot_end)
+        hipLaunchKernelGGL(pt_unpack, dim3((fp.slot_end + 255) / 256), dim3(256), 0, ctx->stream, fp, (const float4 *)d_packed, ctx->d_accum);
+    HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
 

@@ -1,12 +1,19 @@
 """Multi-GPU rendering: one process per GPU, frame tiles interleaved over ranks,
-one RCCL reduce of the radiance buffer to rank 0 (torch.distributed, backend
-"nccl" = RCCL over xGMI).  The reference is single device (src/kernelgl.cpp:76);
-this module is new, mandated by BASELINE.json's north_star.
+one exchange of the radiance (accumulator) buffer to rank 0 over xGMI
+(torch.distributed, backend "nccl" = RCCL).  The reference is single device
+(src/kernelgl.cpp:76); this module is new, mandated by BASELINE.json's north_star.
 
-The path shards naturally: every pixel-sample is independent, so
-the only exchange is the final gather of disjoint tiles, expressed as a sum of
-zero-initialised full-frame buffers (each pixel is non-zero on exactly one rank,
-so the sum is exact and bit-identical to the single-GPU frame).
+The path shards naturally: every pixel-sample is independent, pixels
+keep their whole-frame coordinates, so each pixel is bit-identical to the
+single-GPU render and the only exchange is the final collection of disjoint tiles:
+
+  exchange="gather" (default)  every rank packs the accumulator pixels it owns
+      (1/world of the frame, slot order, rt_pack_accum) and rank 0 gathers and
+      scatters them into its frame (rt_unpack_accum): 33.2 MB·(1−1/N) arrive at
+      rank 0 over N−1 xGMI links in parallel.
+  exchange="reduce"            sum of the zero-initialised full-frame buffers
+      (each pixel is non-zero on exactly one rank, so the sum is exact): the
+      collective BASELINE.json names; moves the whole frame per rank.
 
 torch is plumbing here: process group, device tensors wrapped around the
 library's own HIP buffers (zero copy, via __cuda_array_interface__).
@@ -25,6 +32,27 @@ def tile_owner_map(width, height, world, tile_w=TILE, tile_h=TILE):
     tiles_x = (width + tile_w - 1) // tile_w
     ty, tx = np.meshgrid(np.arange(height) // tile_h, np.arange(width) // tile_w, indexing="ij")
     return (ty * tiles_x + tx) % world
+
+
+def shard_slots(width, height, world, tile_w=TILE, tile_h=TILE):
+    """Pixel slots every rank packs (rt_shard_slots): whole tiles, equal for all ranks."""
+    tiles = ((width + tile_w - 1) // tile_w) * ((height + tile_h - 1) // tile_h)
+    return (tiles + world - 1) // world * tile_w * tile_h
+
+
+def slot_pixels(width, height, rank, world, tile_w=TILE, tile_h=TILE):
+    """Host restatement of slot_to_pixel (csrc/rt_amd.hip): for rank's slots 0..n-1 →
+    (valid mask, y, x).  Slot s = k·tile_area + j lives in tile t = rank + k·world."""
+    n = shard_slots(width, height, world, tile_w, tile_h)
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_total = tiles_x * ((height + tile_h - 1) // tile_h)
+    s = np.arange(n)
+    k, j = s // (tile_w * tile_h), s % (tile_w * tile_h)
+    t = rank + k * world
+    x = (t % tiles_x) * tile_w + j % tile_w
+    y = (t // tiles_x) * tile_h + j // tile_w
+    valid = (t < tiles_total) & (x < width) & (y < height)
+    return valid, np.where(valid, y, 0), np.where(valid, x, 0)
 
 
 def init_process_group(backend=None):
@@ -53,31 +81,80 @@ def reduce_frame(buf, dst=0):
     return buf
 
 
-class ShardedRenderer:
-    """One rank's share of a tile-sharded frame.
-
-    ``tracer`` is this rank's RayTracer (its own GPU).  ``render(camera, spp)`` traces
-    this rank's tiles with the fused kernel, then reduces the linear accumulator
-    (RGB sum + sample count per pixel) to rank 0, where ``resolve`` turns it into the
-    gamma-space image.  Everything is enqueued on torch's current stream.
-    """
+class GpuShard:
+    """Adapter between ShardedRenderer and a RayTracer on this rank's GPU."""
 
     def __init__(self, tracer, rank, world, tile=TILE):
         import torch
         self.torch = torch
         self.tracer, self.rank, self.world = tracer, rank, world
         tracer.setShard(rank, world, tile, tile)
-        tracer.setStream(torch.cuda.current_stream().cuda_stream)
-        self.accum = torch.as_tensor(tracer.deviceAccum(), device="cuda")
+        # One dedicated (non-default) HIP stream carries the library's kernels AND is torch's
+        # current stream while collectives are issued, so RCCL orders itself after the trace
+        # kernels and the unpack/resolve kernels after RCCL — no host synchronisation.
+        self.stream = torch.cuda.Stream()
+        tracer.setStream(self.stream.cuda_stream)
+        self.accum = torch.as_tensor(tracer.deviceAccum(), device="cuda")          # (h, w, 4), zero copy
+        self.slots = tracer.shardSlots(world)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def new_packed(self):
+        import torch
+        return torch.empty((self.slots, 4), dtype=torch.float32, device="cuda")
+
+    def trace(self, camera, first_sample, spp):
+        self.tracer.clear()
+        self.tracer.renderSamples(camera, first_sample, spp)
+
+    def pack(self, out):
+        self.tracer.packAccum(out.data_ptr(), out.numel() * 4)
+
+    def unpack(self, packed, src_rank):
+        self.tracer.unpackAccum(packed.data_ptr(), packed.numel() * 4, src_rank, self.world)
+
+    def resolve(self):
+        self.tracer.resolve()
+
+    def image(self):
+        return self.tracer.transferImage()
+
+
+class ShardedRenderer:
+    """One rank's share of a tile-sharded frame.  ``shard`` is a GpuShard (or any object
+    with its trace / pack / unpack / resolve / accum / new_packed surface — the CPU tests
+    drive this class over gloo with an oracle-backed stand-in).  Everything is enqueued
+    on torch's current stream; nothing here synchronises the host."""
+
+    def __init__(self, shard, rank, world, exchange="gather"):
+        assert exchange in ("gather", "reduce")
+        self.shard, self.rank, self.world, self.exchange = shard, rank, world, exchange
+        if world > 1 and exchange == "gather":
+            import contextlib
+            with (shard.stream_context() if hasattr(shard, "stream_context") else contextlib.nullcontext()):
+                self.send = shard.new_packed()
+                self.recv = [shard.new_packed() for _ in range(world)] if rank == 0 else None
 
     def render(self, camera, spp, first_sample=0):
-        t = self.tracer
-        t.clear()
-        t.renderSamples(camera, first_sample, spp)
-        reduce_frame(self.accum, dst=0)
-        if self.rank == 0:
-            t.resolve()
+        import contextlib
+        import torch.distributed as dist
+        sh = self.shard
+        ctx = sh.stream_context() if hasattr(sh, "stream_context") else contextlib.nullcontext()
+        with ctx:
+            sh.trace(camera, first_sample, spp)
+            if self.world > 1:
+                if self.exchange == "reduce":
+                    reduce_frame(sh.accum, dst=0)
+                else:
+                    sh.pack(self.send)
+                    dist.gather(self.send, self.recv, dst=0)
+                    if self.rank == 0:
+                        for r in range(1, self.world):   # rank 0's own tiles are already in place
+                            sh.unpack(self.recv[r], r)
+            if self.rank == 0:
+                sh.resolve()
 
     def image(self):
         """Gamma-space frame on rank 0 (h, w, 4)."""
-        return self.tracer.transferImage()
+        return self.shard.image()

@@ -26,7 +26,7 @@ SYMBOLS = (
     "rt_set_shard", "rt_render", "rt_render_again", "rt_sample_counter", "rt_clear", "rt_render_spp", "rt_resolve",
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
-    "rt_kernel_ms_history", "rt_device_info", "rt_set_option",
+    "rt_kernel_ms_history", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
 )
 
 
@@ -48,6 +48,13 @@ def load_library(path=LIB_PATH):
     if not os.path.isfile(path):
         raise OSError("%s not found — the HIP library is not built (run __graft_entry__.build()); "
                       "there is no CPU fallback" % path)
+    # PyTorch's ROCm wheel bundles its own libamdhip64.so.7.  A process must hold ONE HIP runtime:
+    # if librt_amd.so pulled in /opt/rocm's copy first, a later `import torch` would find "No HIP
+    # GPUs".  Importing torch first (when it is installed) makes both bind to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for s in SYMBOLS:
         getattr(lib, s)  # AttributeError if the library does not export what the header declares
@@ -86,6 +93,9 @@ def load_library(path=LIB_PATH):
     lib.rt_last_kernel_ms.argtypes = [vp, fp]
     lib.rt_kernel_ms_history.argtypes = [vp, fp, sz, C.POINTER(sz)]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.rt_shard_slots.argtypes = [vp, C.c_int, C.POINTER(u32)]
+    lib.rt_pack_accum.argtypes = [vp, vp, sz]
+    lib.rt_unpack_accum.argtypes = [vp, vp, sz, C.c_int, C.c_int]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.c_char_p, sz]
     if lib.rt_abi_version() != _abi.RT_ABI_VERSION:
         raise OSError("librt_amd.so ABI %d != expected %d" % (lib.rt_abi_version(), _abi.RT_ABI_VERSION))
@@ -192,6 +202,18 @@ class RayTracer:
 
     def setOption(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, int(value)))
+
+    def shardSlots(self, world):
+        n = C.c_uint32()
+        self._check(self._lib.rt_shard_slots(self._ctx, world, C.byref(n)))
+        return n.value
+
+    def packAccum(self, device_ptr, nbytes):
+        """This rank's owned accumulator pixels → device buffer (slot order)."""
+        self._check(self._lib.rt_pack_accum(self._ctx, C.c_void_p(device_ptr), nbytes))
+
+    def unpackAccum(self, device_ptr, nbytes, src_rank, world):
+        self._check(self._lib.rt_unpack_accum(self._ctx, C.c_void_p(device_ptr), nbytes, src_rank, world))
 
     def setStream(self, hip_stream):
         self._check(self._lib.rt_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))

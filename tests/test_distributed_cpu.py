@@ -1,10 +1,9 @@
-"""CPU: the N > 1 path.  (1) the tile→rank ownership map partitions the frame;
-(2) a world_size-2 gloo run of the reduce step rebuilds the unsharded frame
-bit-for-bit from the two ranks' zero-filled shards."""
+"""CPU: the N > 1 path.  (1) the tile→rank ownership map and the slot→pixel map partition
+the frame; (2) a world_size-2 gloo run drives the real ShardedRenderer (both exchange modes)
+with an oracle-backed stand-in for the GPU and must rebuild the unsharded frame bit for bit."""
 import os
 import subprocess
 import sys
-import textwrap
 
 import numpy as np
 import pytest
@@ -14,52 +13,44 @@ import cases
 rt = cases.rt
 
 
+def dist_mod():
+    from importlib import import_module
+    return import_module("opencl-raytracing_amd.distributed")
+
+
 @pytest.mark.parametrize("w,h,world", [(1920, 1080, 8), (173, 99, 2), (64, 48, 3), (7, 5, 4), (3840, 2160, 8)])
 def test_tile_owner_map_partitions_and_balances(w, h, world):
-    from importlib import import_module
-    d = import_module("opencl-raytracing_amd.distributed")
+    d = dist_mod()
     own = d.tile_owner_map(w, h, world)
     assert own.shape == (h, w) and own.min() >= 0 and own.max() < world
     counts = np.bincount(own.reshape(-1), minlength=world)
     assert counts.sum() == w * h
     if w * h >= 64 * 64 * world:
         assert counts.max() - counts.min() <= 64 * (w // 8 + 2)      # within a tile row of each other
-    # matches the kernel's numbering: tile t = ty*tiles_x + tx, owner t % world
     tiles_x = (w + 7) // 8
     assert own[h - 1, w - 1] == (((h - 1) // 8) * tiles_x + (w - 1) // 8) % world
 
 
-WORKER = textwrap.dedent("""
-    import os, sys
-    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
-    import numpy as np, torch, torch.distributed as dist
-    from importlib import import_module
-    import cases
-    from oracle import Oracle
-    d = import_module("opencl-raytracing_amd.distributed")
-    rank, world, _ = d.init_process_group("gloo")
-    assert world == 2 and dist.get_backend() == "gloo"
-    wl = cases.rt.workloads.get("all_kinds", width=96, height=56)
-    table = cases.rt.workloads.make_random_table(cases.SEED)
-    # stand-in for this rank's GPU: the oracle renders the frame, the rank keeps only the tiles it owns
-    full, _ = Oracle().render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=3, threads=2)
-    own = d.tile_owner_map(wl.width, wl.height, world) == rank
-    shard = torch.from_numpy(np.where(own[..., None], full, 0).astype(np.float32))
-    d.reduce_frame(shard, dst=0)
-    if rank == 0:
-        assert np.array_equal(shard.numpy().view(np.uint32), full.view(np.uint32)), "reduced frame differs"
-        print("REDUCE_OK")
-    dist.barrier()
-    dist.destroy_process_group()
-""")
+@pytest.mark.parametrize("w,h,world", [(93, 56, 2), (1920, 1080, 8), (64, 64, 3)])
+def test_slot_pixels_partition(w, h, world):
+    """The host restatement of the kernel's slot→pixel map: the ranks' valid slots cover every
+    pixel exactly once and agree with the tile owner map."""
+    d = dist_mod()
+    seen = np.zeros((h, w), np.int32)
+    own = d.tile_owner_map(w, h, world)
+    for r in range(world):
+        valid, y, x = d.slot_pixels(w, h, r, world)
+        assert len(valid) == d.shard_slots(w, h, world)
+        np.add.at(seen, (y[valid], x[valid]), 1)
+        assert (own[y[valid], x[valid]] == r).all()
+    assert (seen == 1).all()
 
 
-def test_gloo_world2_reduce_rebuilds_frame(built, tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": cases.ROOT})
+def test_gloo_world2_exchange_rebuilds_frame(built):
+    worker = os.path.join(cases.ROOT, "tests", "dist_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29731", str(script)]
+           "127.0.0.1", "--master-port", "29731", worker]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "REDUCE_OK" in out.stdout
+    assert "EXCHANGE_OK gather" in out.stdout and "EXCHANGE_OK reduce" in out.stdout

@@ -174,3 +174,35 @@ def test_prefix_sharing_and_sample_queue_change_no_bit(name, kw, spps):
             assert np.array_equal(out[0][0].view(np.uint32), o[0].view(np.uint32)), spp
             assert out[0][1] == o[1], spp
     t.close()
+
+
+def test_pack_unpack_exchange_with_virtual_ranks():
+    """The compact exchange of the N-GPU path on one GPU: every virtual rank renders its tiles and
+    packs them (rt_pack_accum); a receiver context unpacks all of them (rt_unpack_accum) and must
+    hold the unsharded accumulator bit for bit.  The packed layout equals the host restatement."""
+    import torch
+    from importlib import import_module
+    d = import_module("opencl-raytracing_amd.distributed")
+    wl = rt.workloads.get("all_kinds", width=173, height=99)
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    t.clear(); t.renderSamples(wl.camera, 0, 8); whole = t.readLinear()
+    world = 3
+    recv = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    recv.clear()
+    n = t.shardSlots(world)
+    assert n == d.shard_slots(wl.width, wl.height, world)
+    acc_t = torch.as_tensor(t.deviceAccum(), device="cuda")
+    for r in range(world):
+        t.setShard(r, world, 8, 8)
+        t.clear(); t.renderSamples(wl.camera, 0, 8)
+        packed = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        t.packAccum(packed.data_ptr(), packed.numel() * 4)
+        t.sync()
+        valid, y, x = d.slot_pixels(wl.width, wl.height, r, world)
+        host = acc_t.cpu().numpy()[y, x]
+        host[~valid] = 0
+        assert np.array_equal(packed.cpu().numpy().view(np.uint32), host.view(np.uint32))
+        recv.unpackAccum(packed.data_ptr(), packed.numel() * 4, r, world)
+        recv.sync()
+    assert np.array_equal(recv.readLinear().view(np.uint32), whole.view(np.uint32))
+    t.close(); recv.close()
