@@ -313,6 +313,9 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
 #define RT_OPT_MAX_THREADS_PER_LAUNCH 2 /* split one render call into several kernel launches           */
 #define RT_OPT_SAMPLE_QUEUE 3           /* 1 (default): lanes pull samples from an in-wave queue as their
                                            paths end; 0: one fixed sample set per lane                  */
+#define RT_OPT_ACCEL 4                  /* sphere search: 0 brute force (the reference's loop), 1 (default)
+                                           conservative BVH for scenes of >= 64 spheres, 2 BVH always.
+                                           Same (t, index) winner in every mode                        */
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* ---- measurement --------------------------------------------------------- */
@@ -322,6 +325,10 @@ int rt_set_option(rt_context *ctx, int option, int value);
 int rt_enable_counters(rt_context *ctx, int enable);
 int rt_reset_counters(rt_context *ctx);
 int rt_get_counters(rt_context *ctx, rt_counters *out);
+
+/* Diagnostics of the sphere search since the last reset (counting build only):
+ * out[0] = BVH nodes entered, out[1] = sphere tests actually executed. */
+int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]);
 
 /* Algorithmic bytes of the reference kernel for these counters
  * (SURVEY §8d): 32·t_sphere + 48·t_plane + 64·t_lens + 12·t_model +

@@ -89,15 +89,25 @@ struct DeviceScene {
     const float4 *tex;   // layers × h × w texels
     int tex_w, tex_h, tex_layers;
     uint32_t material_count, sphere_count, sphere_batches, plane_count, lens_count, model_count;
+    // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
+    const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
+    const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
+    const uint32_t *bvh_idx;   // their original indices
+    uint32_t bvh_node_count;
+    float bvh_lo[3], bvh_hi[3];  // bounds of all sphere CENTRES
+    float bvh_rmax;              // largest radius
 };
 
 // per-lane work counters (only in COUNT builds)
+#define PT_N_COUNTERS 16
 struct LaneCounters {
-    uint32_t c[14];
+    uint32_t c[PT_N_COUNTERS];
 };
 enum {
     CN_SAMPLES, CN_BOUNCES, CN_T_SPHERE, CN_T_PLANE, CN_T_LENS, CN_T_MODEL, CN_T_MESH, CN_T_TRI, CN_H_TRI,
-    CN_H_BOUNCE, CN_N_SCATTER, CN_N_DIELECTRIC, CN_N_TEXFETCH, CN_IMAGE_READS
+    CN_H_BOUNCE, CN_N_SCATTER, CN_N_DIELECTRIC, CN_N_TEXFETCH, CN_IMAGE_READS,
+    CN_DBG_BVH_NODES,   // diagnostics (rt_get_debug_counters): BVH nodes entered
+    CN_DBG_BVH_TESTS    // sphere tests actually executed (BVH leaves + brute-force fallback)
 };
 
 // What a device function needs besides the scene: the workgroup's LDS copy of
@@ -189,6 +199,107 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     return t;  // accepted roots are >= MIN_DISTANCE > 0
 }
 
+// ---- sphere BVH -------------------------------------------------------------------
+// The reference tests every sphere on every bounce (:327-333).  For large sphere counts
+// the same answer — min over spheres of (t, index), t from the very same sphere_t()
+// arithmetic — is found through a bounding-volume hierarchy.  It is an acceleration
+// only if it can never drop a sphere the reference would have hit, so the culling is
+// conservative by construction (DESIGN.md "sphere BVH"):
+//   * hitSphere can only succeed when its computed discriminant b² − (|oc|² − r²) is > 0.
+//     Its rounding error is below 16·2^-24·|oc|², and for a direction of length² dd ≠ 1 the
+//     formula is the reference's own (non-geometric) one: it succeeds iff the LINE passes
+//     within sqrt(r²/dd + |oc|²(1 − 1/dd)) of the centre.  Both are covered by inflating a
+//     node's box by m = sqrt(c·2)·dfar with c = 2e-6 + 2|dd − 1|/min(dd, 1) and dfar the
+//     largest distance from the origin to the box (|oc| and r of every sphere inside are
+//     <= dfar), plus rounding slack of the slab test itself;
+//   * a node is skipped on distance only if its entry is beyond the best t by a margin;
+//   * candidates are compared by (t, original index), so ties resolve as in the
+//     reference's in-order scan with strict '<';
+//   * rays whose direction is far from unit length (or NaN) take the brute-force loop.
+// Traversal is stackless and ORDERED (near child first, so the best-t bound prunes the far
+// side): nodes carry their parent, siblings are adjacent (left child at an odd index), and a
+// three-state walk (from parent / from sibling / from child) replaces the stack.
+//   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = parent | split_axis << 28;
+//   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
+template <bool COUNT>
+PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, uint32_t &best_id, LaneCounters *cn) {
+    float dd = dot(r.d, r.d);
+    float c_ray = 2.0e-6f + 2.0f * fabsf(dd - 1.0f) / fminf(dd, 1.0f);
+    float k_ray = sqrtf(2.0f * c_ray) * 1.02f;   // margin per unit of distance to the node
+    float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+    V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    // which child is nearer along each axis: bit k set → the RIGHT child (higher coordinates) first
+    uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
+
+    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
+    uint32_t cur = 0;
+    int state = FROM_PARENT;
+    const uint32_t n_nodes = sc.bvh_node_count;
+    for (uint32_t guard = 0; guard < 3u * n_nodes + 8u; guard++) {  // every node is entered at most 3 times
+        float4 a = sc.bvh_nodes[2 * cur], b = sc.bvh_nodes[2 * cur + 1];
+        uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
+        uint32_t parent = A & 0x0FFFFFFFu;
+        uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
+        if (state == FROM_CHILD) {
+            if (cur == 0) break;
+            // was `cur` the near child of its parent?  then its sibling (the far child) is next
+            float4 pa = sc.bvh_nodes[2 * parent], pb = sc.bvh_nodes[2 * parent + 1];
+            uint32_t pleft = __float_as_uint(pb.w), paxis = (__float_as_uint(pa.w) >> 28) & 3u;
+            uint32_t pnear = pleft + ((far_first >> paxis) & 1u);
+            if (cur == pnear) {
+                cur = sibling;
+                state = FROM_SIBLING;
+            } else {
+                cur = parent;
+            }
+            continue;
+        }
+        if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
+        // entering `cur` from its parent or its sibling: slab test against the inflated box
+        // (fminf/fmaxf drop the NaN of 0·inf)
+        float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
+        float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
+        float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
+        float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;  // approximate sqrt, rounded up
+        float m = k_ray * dfar + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
+        float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
+        float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
+        t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
+        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
+        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        bool miss = tmin > tmax + fabsf(tmax) * 1.0e-5f + 1.0e-4f   // the line misses the box
+                    || tmax < -1.0e-2f                               // box entirely behind the origin
+                    || tmin > best_t * 1.00001f + 1.0e-2f;           // box entirely beyond the best hit
+        bool leaf = (B & 0x80000000u) != 0;
+        if (!miss && leaf) {
+            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
+                float t = sphere_t(r, sc.bvh_sph[first + k]);
+                uint32_t idx = sc.bvh_idx[first + k];
+                if (t > 0.0f && (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK)))) {
+                    best_t = t;
+                    best_id = K_SPHERE | idx;
+                }
+            }
+        }
+        if (!miss && !leaf) {  // descend to the near child
+            uint32_t axis = (A >> 28) & 3u;
+            cur = B + ((far_first >> axis) & 1u);
+            state = FROM_PARENT;
+        } else if (cur == 0) {
+            break;  // the root is a leaf or was missed
+        } else if (state == FROM_PARENT) {
+            cur = sibling;
+            state = FROM_SIBLING;
+        } else {
+            cur = parent;
+            state = FROM_CHILD;
+        }
+    }
+}
+
 // :176-194
 PT_DEV float plane_t(const Ray &r, V3 p0, V3 n) {
     float a = dot(r.d, n);
@@ -264,8 +375,16 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
     uint32_t best_face = 0, best_mat = 0;
     float best_u = 0.0f, best_v = 0.0f;
 
-    // spheres: wave-uniform index → scalar loads; a batch of 4 in flight while 4 are tested
-    if (sc.sphere_batches) {
+    // spheres: through the BVH when one was built, for lanes whose direction is (nearly) unit length
+    bool brute = true;
+    if (sc.bvh_node_count) {
+        float dd = dot(r.d, r.d);
+        brute = !(fabsf(dd - 1.0f) < 0.25f);  // also catches NaN; the margin m covers any smaller deviation
+        if (!brute) hit_spheres_bvh<COUNT>(sc, r, best_t, best_id, c.cn);
+    }
+    // brute force: wave-uniform index → scalar loads; a batch of 4 in flight while 4 are tested
+    if (COUNT && brute) c.cn->c[CN_DBG_BVH_TESTS] += sc.sphere_count;
+    if (brute && sc.sphere_batches) {
         const float4 *sp = sc.sph4;
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
         for (uint32_t b = 0; b < sc.sphere_batches; b++) {

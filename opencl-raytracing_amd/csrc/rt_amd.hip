@@ -5,6 +5,7 @@
 // device rt_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -55,7 +56,7 @@ PT_DEV void flush_counters(const LaneCounters &cn, unsigned long long *counters,
     if (!COUNT) return;
     unsigned long long *row = counters + (size_t)(blockIdx.x % COUNTER_REPLICAS) * COUNTER_STRIDE;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
+    for (int i = 0; i < PT_N_COUNTERS; i++) {
         uint32_t v = cn.c[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -65,7 +66,7 @@ PT_DEV void flush_counters(const LaneCounters &cn, unsigned long long *counters,
 
 PT_DEV void zero_counters(LaneCounters &cn) {
 #pragma unroll
-    for (int i = 0; i < 14; i++) cn.c[i] = 0;
+    for (int i = 0; i < PT_N_COUNTERS; i++) cn.c[i] = 0;
 }
 
 // xor-butterfly over the g lanes of a pixel group: a fixed summation tree
@@ -490,6 +491,132 @@ void make_table(uint64_t seed, float *out) {
     }
 }
 
+#define ACCEL_MIN_SPHERES 64
+
+// Sphere BVH (see hit_spheres_bvh): binned surface-area-heuristic splits (16 bins per axis over the
+// centroids; median split when no bin boundary separates them), leaves of <= 4 spheres; children
+// are allocated in adjacent pairs (left at an odd index, lower coordinates along the split axis),
+// every node records its parent and split axis for the stackless ordered traversal.
+struct BvhBuild {
+    const rt_sphere *sph;
+    std::vector<uint32_t> order;
+    std::vector<float4> nodes;   // 2 per node
+    std::vector<float4> leaf_sph;
+    std::vector<uint32_t> leaf_idx;
+
+    void bounds(uint32_t b, uint32_t e, float lo[3], float hi[3]) const {
+        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (uint32_t i = b; i < e; i++) {
+            const rt_sphere &s = sph[order[i]];
+            const float c[3] = {s.pos.x, s.pos.y, s.pos.z};
+            float r = std::fabs(s.r);
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::fmin(lo[k], c[k] - r);
+                hi[k] = std::fmax(hi[k], c[k] + r);
+            }
+        }
+    }
+    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e) {
+        float lo[3], hi[3];
+        bounds(b, e, lo, hi);
+        uint32_t A = parent, B;
+        if (e - b <= 4) {
+            uint32_t first = (uint32_t)leaf_sph.size();
+            for (uint32_t i = b; i < e; i++) {
+                const rt_sphere &s = sph[order[i]];
+                volatile float r2 = s.r * s.r;
+                leaf_sph.push_back(make_float4(s.pos.x, s.pos.y, s.pos.z, r2));
+                leaf_idx.push_back(order[i]);
+            }
+            B = 0x80000000u | ((e - b) << 28) | first;
+        } else {
+            float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = b; i < e; i++) {
+                const rt_sphere &s = sph[order[i]];
+                const float c[3] = {s.pos.x, s.pos.y, s.pos.z};
+                for (int k = 0; k < 3; k++) { clo[k] = std::fmin(clo[k], c[k]); chi[k] = std::fmax(chi[k], c[k]); }
+            }
+            int ax = 0;
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[ax] - clo[ax]) ax = k;
+            uint32_t mid = b + (e - b) / 2;
+            const rt_sphere *sp = sph;
+            // binned SAH: cost(split) = area(L)·|L| + area(R)·|R| over 15 boundaries × 3 axes
+            constexpr int NB = 16;
+            double best_cost = INFINITY;
+            int best_ax = -1, best_bin = -1;
+            for (int k = 0; k < 3; k++) {
+                float ext = chi[k] - clo[k];
+                if (!(ext > 0.0f)) continue;
+                struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
+                for (auto &bn : bins) { for (int q = 0; q < 3; q++) { bn.lo[q] = INFINITY; bn.hi[q] = -INFINITY; } bn.n = 0; }
+                for (uint32_t i = b; i < e; i++) {
+                    const rt_sphere &s = sph[order[i]];
+                    const float c[3] = {s.pos.x, s.pos.y, s.pos.z};
+                    int bi = (int)((c[k] - clo[k]) / ext * NB);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    float r = std::fabs(s.r);
+                    for (int q = 0; q < 3; q++) { bins[bi].lo[q] = std::fmin(bins[bi].lo[q], c[q] - r); bins[bi].hi[q] = std::fmax(bins[bi].hi[q], c[q] + r); }
+                    bins[bi].n++;
+                }
+                auto area = [](const float *l, const float *h) {
+                    double dx = (double)h[0] - l[0], dy = (double)h[1] - l[1], dz = (double)h[2] - l[2];
+                    return dx < 0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+                };
+                double right_cost[NB];
+                float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t rn = 0;
+                for (int j = NB - 1; j > 0; j--) {
+                    for (int q = 0; q < 3; q++) { rl[q] = std::fmin(rl[q], bins[j].lo[q]); rh[q] = std::fmax(rh[q], bins[j].hi[q]); }
+                    rn += bins[j].n;
+                    right_cost[j] = rn ? area(rl, rh) * rn : INFINITY;
+                }
+                float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t ln = 0;
+                for (int j = 0; j < NB - 1; j++) {
+                    for (int q = 0; q < 3; q++) { ll[q] = std::fmin(ll[q], bins[j].lo[q]); lh[q] = std::fmax(lh[q], bins[j].hi[q]); }
+                    ln += bins[j].n;
+                    if (ln == 0 || ln == e - b) continue;
+                    double cost = area(ll, lh) * ln + right_cost[j + 1];
+                    if (cost < best_cost) { best_cost = cost; best_ax = k; best_bin = j; }
+                }
+            }
+            if (best_ax >= 0) {
+                ax = best_ax;
+                float ext = chi[ax] - clo[ax], base = clo[ax];
+                int bb = best_bin;
+                auto it = std::partition(order.begin() + b, order.begin() + e, [sp, ax, ext, base, bb](uint32_t i) {
+                    const float *ci = &sp[i].pos.x;
+                    int bi = (int)((ci[ax] - base) / ext * NB);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    return bi <= bb;
+                });
+                mid = (uint32_t)(it - order.begin());
+            }
+            if (best_ax < 0 || mid == b || mid == e) {  // coincident centroids: median split by index
+                mid = b + (e - b) / 2;
+                std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [sp, ax](uint32_t i, uint32_t j) {
+                    const float *ci = &sp[i].pos.x, *cj = &sp[j].pos.x;
+                    return ci[ax] < cj[ax] || (ci[ax] == cj[ax] && i < j);
+                });
+            }
+            uint32_t left = (uint32_t)(nodes.size() / 2);  // odd: the root is node 0 and pairs follow
+            nodes.resize(nodes.size() + 4);
+            A |= (uint32_t)ax << 28;
+            B = left;
+            fill(left, me, b, mid);
+            fill(left + 1, me, mid, e);
+        }
+        nodes[2 * me] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        nodes[2 * me + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        memcpy(&nodes[2 * me].w, &A, 4);
+        memcpy(&nodes[2 * me + 1].w, &B, 4);
+    }
+    void build(uint32_t b, uint32_t e) {
+        nodes.resize(2);
+        fill(0, 0, b, e);
+    }
+};
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -529,6 +656,11 @@ struct rt_context {
     DevBuf<rt_sphere> spheres;
     DevBuf<float4> sph4;
     uint32_t sphere_batches = 0;
+    DevBuf<float4> bvh_nodes, bvh_sph;
+    DevBuf<uint32_t> bvh_idx;
+    uint32_t bvh_node_count = 0;
+    float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0}, bvh_rmax = 0;
+    int accel = 1;  // RT_OPT_ACCEL: 0 brute force, 1 BVH for >= ACCEL_MIN_SPHERES spheres, 2 always BVH
     DevBuf<rt_plane> planes;
     DevBuf<rt_lens> lenses;
     DevBuf<rt_float3> vertices;
@@ -609,6 +741,13 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.sph4 = ctx->sph4.p;
     s.sphere_batches = ctx->sphere_batches;
     s.material_count = (uint32_t)ctx->materials.n;
+    bool use_bvh = ctx->bvh_node_count && (ctx->accel == 2 || (ctx->accel == 1 && ctx->spheres.n >= ACCEL_MIN_SPHERES));
+    s.bvh_nodes = ctx->bvh_nodes.p;
+    s.bvh_sph = ctx->bvh_sph.p;
+    s.bvh_idx = ctx->bvh_idx.p;
+    s.bvh_node_count = use_bvh ? ctx->bvh_node_count : 0;
+    for (int k = 0; k < 3; k++) { s.bvh_lo[k] = ctx->bvh_lo[k]; s.bvh_hi[k] = ctx->bvh_hi[k]; }
+    s.bvh_rmax = ctx->bvh_rmax;
     s.planes = ctx->planes.p;
     s.lenses = ctx->lenses.p;
     s.vertices = ctx->vertices.p;
@@ -849,6 +988,9 @@ void rt_destroy(rt_context *ctx) {
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_live) (void)hipFree(ctx->d_live);
     ctx->sph4.release();
+    ctx->bvh_nodes.release();
+    ctx->bvh_sph.release();
+    ctx->bvh_idx.release();
     for (int i = 0; i < rt_context::EV_RING; i++)
         for (int k = 0; k < 2; k++)
             if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
@@ -936,6 +1078,31 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         }
         HIP_TRY(ctx, ctx->sph4.upload(v.data(), v.size()));
         ctx->sphere_batches = batches;
+    }
+    ctx->bvh_node_count = 0;
+    if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {
+        bool finite = true;
+        for (uint32_t i = 0; i < d->sphere_count && finite; i++)
+            finite = std::isfinite(d->spheres[i].pos.x) && std::isfinite(d->spheres[i].pos.y) &&
+                     std::isfinite(d->spheres[i].pos.z) && std::isfinite(d->spheres[i].r);
+        if (finite) {  // non-finite spheres: no BVH, the brute-force loop handles them as the reference does
+            BvhBuild bb;
+            bb.sph = d->spheres;
+            bb.order.resize(d->sphere_count);
+            for (uint32_t i = 0; i < d->sphere_count; i++) bb.order[i] = i;
+            bb.build(0, d->sphere_count);
+            HIP_TRY(ctx, ctx->bvh_nodes.upload(bb.nodes.data(), bb.nodes.size()));
+            HIP_TRY(ctx, ctx->bvh_sph.upload(bb.leaf_sph.data(), bb.leaf_sph.size()));
+            HIP_TRY(ctx, ctx->bvh_idx.upload(bb.leaf_idx.data(), bb.leaf_idx.size()));
+            ctx->bvh_node_count = (uint32_t)(bb.nodes.size() / 2);
+            ctx->bvh_rmax = 0;
+            for (int k = 0; k < 3; k++) { ctx->bvh_lo[k] = INFINITY; ctx->bvh_hi[k] = -INFINITY; }
+            for (uint32_t i = 0; i < d->sphere_count; i++) {
+                const float c[3] = {d->spheres[i].pos.x, d->spheres[i].pos.y, d->spheres[i].pos.z};
+                for (int k = 0; k < 3; k++) { ctx->bvh_lo[k] = std::fmin(ctx->bvh_lo[k], c[k]); ctx->bvh_hi[k] = std::fmax(ctx->bvh_hi[k], c[k]); }
+                ctx->bvh_rmax = std::fmax(ctx->bvh_rmax, std::fabs(d->spheres[i].r));
+            }
+        }
     }
     HIP_TRY(ctx, ctx->planes.upload(d->planes, d->plane_count));
     HIP_TRY(ctx, ctx->lenses.upload(d->lenses, d->lens_count));
@@ -1207,6 +1374,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     switch (option) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
         case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
+        case RT_OPT_ACCEL:
+            if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_ACCEL takes 0, 1 or 2");
+            ctx->accel = value;
+            return RT_OK;
         case RT_OPT_MAX_THREADS_PER_LAUNCH:
             if (value < 256) return fail(ctx, RT_EINVAL, "max threads per launch must be >= 256");
             ctx->max_threads_per_launch = (uint32_t)value;
@@ -1232,6 +1403,20 @@ int rt_get_counters(rt_context *ctx, rt_counters *out) {
     for (int i = 0; i < 14; i++) {
         o[i] = 0;
         for (int r = 0; r < COUNTER_REPLICAS; r++) o[i] += h[(size_t)r * COUNTER_STRIDE + i];
+    }
+    return RT_OK;
+}
+
+int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]) {
+    if (!ctx || !out) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<unsigned long long> h(COUNTER_REPLICAS * COUNTER_STRIDE);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = out[1] = 0;
+    for (int r = 0; r < COUNTER_REPLICAS; r++) {
+        out[0] += h[(size_t)r * COUNTER_STRIDE + 14];
+        out[1] += h[(size_t)r * COUNTER_STRIDE + 15];
     }
     return RT_OK;
 }

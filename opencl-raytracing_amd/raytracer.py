@@ -27,6 +27,7 @@ SYMBOLS = (
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
     "rt_kernel_ms_history", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
+    "rt_get_debug_counters",
 )
 
 
@@ -198,7 +199,7 @@ class RayTracer:
     def setShard(self, rank, world, tile_w=8, tile_h=8):
         self._check(self._lib.rt_set_shard(self._ctx, rank, world, tile_w, tile_h))
 
-    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE = 1, 2, 3
+    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL = 1, 2, 3, 4
 
     def setOption(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, int(value)))
@@ -301,6 +302,12 @@ class RayTracer:
         c = _abi.Counters()
         self._check(self._lib.rt_get_counters(self._ctx, C.byref(c)))
         return c
+
+    def debugCounters(self):
+        """(BVH nodes entered, sphere tests executed) since resetCounters(), counting build only."""
+        out = (C.c_uint64 * 2)()
+        self._check(self._lib.rt_get_debug_counters(self._ctx, out))
+        return int(out[0]), int(out[1])
 
     def lastKernelMs(self):
         ms = C.c_float()

@@ -206,3 +206,76 @@ def test_pack_unpack_exchange_with_virtual_ranks():
         recv.sync()
     assert np.array_equal(recv.readLinear().view(np.uint32), whole.view(np.uint32))
     t.close(); recv.close()
+
+
+@pytest.mark.parametrize("name,kw,spp", [
+    ("c4", dict(width=160, height=90, n_spheres=20000), 4),
+    ("c4", dict(width=64, height=36, n_spheres=100000), 2),
+    ("c2", dict(width=160, height=90), 16),
+    ("all_kinds", dict(width=160, height=96), 8),
+])
+def test_sphere_bvh_changes_no_bit(name, kw, spp):
+    """RT_OPT_ACCEL: the conservative sphere BVH against the reference's brute-force loop —
+    identical accumulators, probes and counters (the counters price the reference's logical
+    work, so they do not depend on the search structure)."""
+    wl = rt.workloads.get(name, **kw)
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    rng = np.random.RandomState(11)
+    n = 4000
+    xs, ys, ss = rng.randint(0, wl.width, n), rng.randint(0, wl.height, n), rng.randint(0, 4096, n)
+    out = []
+    for accel in (0, 2):
+        t.setOption(t.OPT_ACCEL, accel)
+        t.enableCounters(True)
+        t.resetCounters()
+        t.clear()
+        t.renderSamples(wl.camera, 0, spp)
+        lin = t.readLinear()
+        cn = t.counters().as_dict()
+        t.enableCounters(False)
+        t.render(wl.camera)
+        t.renderAgain(wl.camera)
+        out.append((lin, cn, t.transferImage(), t.traceSamples(wl.camera, xs, ys, ss)))
+    for k in (0, 2, 3):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    assert out[0][1] == out[1][1]
+    t.close()
+
+
+def test_sphere_bvh_adversarial_scene(oracle, table):
+    """Spheres that stress the conservative culling: tiny and huge radii, concentric and touching
+    spheres, duplicates (index tie-break), centres far from the camera, glass (non-unit refracted
+    directions).  BVH result == brute force == oracle probes."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.9, 0.9, 0.9), 1)
+    s.addMaterial(rt._abi.T_REFRACTIVE, (1, 1, 1), 1.5)
+    s.addMaterial(rt._abi.T_REFLECTIVE, (1, 1, 1), 0.9)
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.3)
+    u = rt.workloads.uniforms(3000, 5)
+    pos = np.stack([u[:, 0] * 40 - 20, u[:, 1] * 8 - 4, u[:, 2] * 40 - 10], 1).astype(np.float32)
+    rad = (0.02 + 0.6 * u[:, 3] ** 3).astype(np.float32)
+    mat = (np.arange(3000) % 5).astype(np.uint32)
+    s.addSpheres(pos, rad, mat)
+    s.addSpheres(pos[:200], rad[:200], (mat[:200] + 1) % 5)                 # exact duplicates: lower index must win
+    s.addSpheres(pos[200:400], rad[200:400] * np.float32(1.5), mat[200:400])  # concentric shells
+    s.addSphere((0, -500, 0), 400, 3)                                        # huge light
+    s.addSphere((900, 0, 900), 50, 0)                                        # far away
+    s.addSphere((0, 0, 5), 1e-4, 2)                                          # below MIN_DISTANCE scale
+    s.addPlane((0, 5, 0), (0, 1, 0), 0)
+    w, h = 192, 108
+    cam = rt.Camera(70, w / h, (0.3, -1.0, -14.0), 3.0, 4.0).transferData()
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    frames = []
+    for accel in (0, 2):
+        t.setOption(t.OPT_ACCEL, accel)
+        t.clear(); t.renderSamples(cam, 0, 16)
+        frames.append(t.readLinear())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    rng = np.random.RandomState(5)
+    n = 3000
+    xs, ys, ss = rng.randint(0, w, n), rng.randint(0, h, n), rng.randint(0, 500, n)
+    got = t.traceSamples(cam, xs, ys, ss)
+    exp, _ = oracle.samples(s, cam, table, w, h, xs, ys, ss)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    t.close()
