@@ -89,6 +89,11 @@ struct DeviceScene {
     const float4 *tex;   // layers × h × w texels
     int tex_w, tex_h, tex_layers;
     uint32_t material_count, sphere_count, sphere_batches, plane_count, lens_count, model_count;
+    // per-face records of all meshes, 3 float4 each: (A.xyz, e1.x), (e1.yz, e2.xy), (e2.z, n.xyz) with
+    // e1 = B−A, e2 = C−A, n = normalize(cross(e1,e2)) computed once at upload with the same binary32
+    // operations hitTriangle performs per test (:264-265,285); faces of mesh m start at mesh_face_base[m]
+    const float4 *faces;
+    const uint32_t *mesh_face_base;
     // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
     const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
     const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
@@ -424,28 +429,32 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             uint32_t mi = model.mesh_anchor + k;
             const rt_mesh &mesh = sc.meshes[mi];
             if (COUNT) c.cn->c[CN_T_MESH]++;
-            // hitMeshOut: scan faces until this lane has its first front-facing hit
+            // hitMeshOut: scan faces until this lane has its first front-facing hit.  The face
+            // records come through scalar loads (wave-uniform index), the next one in flight
+            // while the current one is tested.
             bool found = false;
             float ft = 0.0f, fu = 0.0f, fv = 0.0f;
             uint32_t fface = 0;
+            const float4 *fr = sc.faces + 3u * (size_t)sc.mesh_face_base[mi];
+            float4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
             for (uint32_t f = 0; f < mesh.face_count; f++) {
-                if (found) continue;  // this lane is done with the mesh; others keep scanning
-                if (COUNT) c.cn->c[CN_T_TRI]++;
-                const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * f;
-                V3 A = ld3(sc.vertices[mesh.vertex_anchor + ib[0]]);
-                V3 B = ld3(sc.vertices[mesh.vertex_anchor + ib[1]]);
-                V3 C = ld3(sc.vertices[mesh.vertex_anchor + ib[2]]);
-                V3 e1 = B - A, e2 = C - A;
-                float u, v;
-                float t = triangle_t(r, A, e1, e2, &u, &v);
-                if (t > 0.0f) {
-                    if (COUNT) c.cn->c[CN_H_TRI]++;
-                    V3 n = normalize(cross(e1, e2));
-                    if (dot(n, r.d) < 0.0f) {
-                        found = true;
-                        ft = t; fu = u; fv = v; fface = f;
+                fr += 3;  // the array ends with a dummy record, so this prefetch stays in bounds
+                float4 p0 = fr[0], p1 = fr[1], p2 = fr[2];
+                if (!found) {  // a lane that has its face idles while the others keep scanning
+                    if (COUNT) c.cn->c[CN_T_TRI]++;
+                    V3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+                    float u, v;
+                    float t = triangle_t(r, A, e1, e2, &u, &v);
+                    if (t > 0.0f) {
+                        if (COUNT) c.cn->c[CN_H_TRI]++;
+                        V3 n = mk(q2.y, q2.z, q2.w);
+                        if (dot(n, r.d) < 0.0f) {
+                            found = true;
+                            ft = t; fu = u; fv = v; fface = f;
+                        }
                     }
                 }
+                q0 = p0; q1 = p1; q2 = p2;
             }
             if (found && ft < model_best) {
                 model_best = ft;
@@ -488,8 +497,8 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         const rt_mesh &mesh = sc.meshes[idx];
         const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * best_face;
         uint32_t ia = mesh.vertex_anchor + ib[0], ibx = mesh.vertex_anchor + ib[1], ic = mesh.vertex_anchor + ib[2];
-        V3 A = ld3(sc.vertices[ia]), B = ld3(sc.vertices[ibx]), C = ld3(sc.vertices[ic]);
-        hit.n = normalize(cross(B - A, C - A));  // :285
+        float4 fq = sc.faces[3u * ((size_t)sc.mesh_face_base[idx] + best_face) + 2];
+        hit.n = mk(fq.y, fq.z, fq.w);  // normalize(cross(e1, e2)), :285, precomputed per face
         rt_float2 ua = sc.uvs[ia], ub = sc.uvs[ibx], uc = sc.uvs[ic];
         float wgt = 1.0f - best_u - best_v;  // :102
         hit.u = (ua.x * wgt + ub.x * best_u) + uc.x * best_v;

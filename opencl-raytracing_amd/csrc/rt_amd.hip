@@ -656,6 +656,8 @@ struct rt_context {
     DevBuf<rt_sphere> spheres;
     DevBuf<float4> sph4;
     uint32_t sphere_batches = 0;
+    DevBuf<float4> faces;
+    DevBuf<uint32_t> mesh_face_base;
     DevBuf<float4> bvh_nodes, bvh_sph;
     DevBuf<uint32_t> bvh_idx;
     uint32_t bvh_node_count = 0;
@@ -741,6 +743,8 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.sph4 = ctx->sph4.p;
     s.sphere_batches = ctx->sphere_batches;
     s.material_count = (uint32_t)ctx->materials.n;
+    s.faces = ctx->faces.p;
+    s.mesh_face_base = ctx->mesh_face_base.p;
     bool use_bvh = ctx->bvh_node_count && (ctx->accel == 2 || (ctx->accel == 1 && ctx->spheres.n >= ACCEL_MIN_SPHERES));
     s.bvh_nodes = ctx->bvh_nodes.p;
     s.bvh_sph = ctx->bvh_sph.p;
@@ -988,6 +992,8 @@ void rt_destroy(rt_context *ctx) {
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_live) (void)hipFree(ctx->d_live);
     ctx->sph4.release();
+    ctx->faces.release();
+    ctx->mesh_face_base.release();
     ctx->bvh_nodes.release();
     ctx->bvh_sph.release();
     ctx->bvh_idx.release();
@@ -1078,6 +1084,37 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         }
         HIP_TRY(ctx, ctx->sph4.upload(v.data(), v.size()));
         ctx->sphere_batches = batches;
+    }
+    {
+        // per-face records (see DeviceScene::faces): the same binary32 operations hitTriangle performs
+        std::vector<uint32_t> base(d->mesh_count ? d->mesh_count : 1, 0u);
+        size_t total = 0;
+        for (uint32_t m = 0; m < d->mesh_count; m++) { base[m] = (uint32_t)total; total += d->meshes[m].face_count; }
+        if (total >= (1ull << 31)) return fail(ctx, RT_EINVAL, "too many faces");
+        std::vector<float4> fr(3 * (total + 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        for (uint32_t m = 0; m < d->mesh_count; m++) {
+            const rt_mesh &me = d->meshes[m];
+            for (uint32_t f = 0; f < me.face_count; f++) {
+                const uint32_t *ib = d->indices + me.index_anchor + 3u * f;
+                const rt_float3 &A = d->vertices[me.vertex_anchor + ib[0]], &B = d->vertices[me.vertex_anchor + ib[1]],
+                                &C = d->vertices[me.vertex_anchor + ib[2]];
+                volatile float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
+                volatile float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
+                volatile float p1 = e1y * e2z, p2 = e1z * e2y, p3 = e1z * e2x, p4 = e1x * e2z, p5 = e1x * e2y, p6 = e1y * e2x;
+                volatile float cx = p1 - p2, cy = p3 - p4, cz = p5 - p6;          // cross(e1, e2)
+                volatile float xx = cx * cx, yy = cy * cy, zz = cz * cz;
+                volatile float s2 = xx + yy;
+                volatile float s3 = s2 + zz;                                        // dot = (x*x + y*y) + z*z
+                volatile float len = std::sqrt((float)s3);
+                volatile float nx = cx / len, ny = cy / len, nz = cz / len;          // normalize
+                float4 *q = &fr[3 * ((size_t)base[m] + f)];
+                q[0] = make_float4(A.x, A.y, A.z, e1x);
+                q[1] = make_float4(e1y, e1z, e2x, e2y);
+                q[2] = make_float4(e2z, nx, ny, nz);
+            }
+        }
+        HIP_TRY(ctx, ctx->faces.upload(fr.data(), fr.size()));
+        HIP_TRY(ctx, ctx->mesh_face_base.upload(base.data(), d->mesh_count));
     }
     ctx->bvh_node_count = 0;
     if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {
