@@ -65,11 +65,10 @@ def cpu_baseline(wl, table, budget_s=20.0):
     ref = Reference() if kind == "reference" else None
     orc = Oracle()
 
-    def run(bands, rows, spp):
-        """`rows` consecutive rows starting at each y in `bands`, all columns, `spp` samples."""
+    def run(regions, spp):
+        """trace + (spp-1) retrace on each (x0, y0, cw, ch) region."""
         t0 = time.perf_counter()
-        for y in bands:
-            region = (0, y, wl.width, rows)
+        for region in regions:
             if ref is not None:
                 ref.progressive(wl.scene, wl.camera, table, wl.width, wl.height, spp, threads, region=region)
             else:
@@ -77,22 +76,36 @@ def cpu_baseline(wl, table, budget_s=20.0):
                            threads=threads)
         return time.perf_counter() - t0
 
-    # bands of `threads` rows spread evenly from top to bottom of the frame (sky, horizon,
-    # floor all represented); calibrate at 1 spp, then size the band count to the budget
-    rows = min(threads, wl.height)
-    max_bands = max(1, wl.height // rows)
-    cal_bands = [int(i * (wl.height - rows) / 7) for i in range(8)] if max_bands >= 8 else [0]
-    t_cal = max(run(cal_bands, rows, 1), 1e-4)
-    per_sample_cpu = t_cal * threads / (wl.width * rows * len(cal_bands))   # core-seconds per pixel-sample
-    spp = wl.spp
-    n_bands = int(budget_s / max(per_sample_cpu * wl.width * rows * spp, 1e-9))
-    n_bands = max(1, min(max_bands, n_bands))
-    bands = [int(i * (wl.height - rows) / max(n_bands - 1, 1)) for i in range(n_bands)]
-    wall = run(bands, rows, spp)
-    samples = wl.width * rows * n_bands * spp
-    return {"value": round(samples / wall / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": "%d band(s) of %d rows spread over the %dx%d frame, %d spp = %.1f M pixel-samples, %.1f s wall"
-                      % (n_bands, rows, wl.width, wl.height, spp, samples / 1e6, wall)}
+    W, H, spp = wl.width, wl.height, wl.spp
+    rows = min(threads, H)
+
+    def bands(n, cw):
+        """n bands of `rows` rows × cw columns, spread evenly from top to bottom (sky, horizon, floor)."""
+        x0 = (W - cw) // 2
+        return [(x0, int(i * (H - rows) / max(n - 1, 1)) if n > 1 else (H - rows) // 2, cw, rows) for i in range(n)]
+
+    # calibrate the cost per pixel-sample on a growing probe (a 100k-sphere bounce costs ~1 ms of CPU)
+    cw, t_cal = 4, 0.0
+    while True:
+        t_cal = run(bands(4, cw), 1)
+        if t_cal > 0.3 or cw >= W:
+            break
+        cw = min(W, cw * 4)
+    core_s_per_sample = max(t_cal, 1e-4) * threads / (4 * rows * cw)
+    n_target = budget_s / core_s_per_sample                      # pixel-samples the budget buys
+    max_bands = max(1, H // rows)
+    if n_target >= W * rows * spp:                               # whole-width bands at full spp
+        nb, cw_s, spp_s = int(min(max_bands, n_target // (W * rows * spp))), W, spp
+    elif n_target >= 16 * rows * spp:                            # one narrower band at full spp
+        nb, cw_s, spp_s = 1, int(n_target // (rows * spp)), spp
+    else:                                                        # a 16-column band at reduced spp
+        nb, cw_s, spp_s = 1, 16, int(max(1, n_target // (16 * rows)))
+    regions = bands(nb, cw_s)
+    wall = run(regions, spp_s)
+    samples = nb * rows * cw_s * spp_s
+    return {"value": round(samples / wall / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": "%d band(s) of %d rows x %d columns of the %dx%d frame, %d of %d spp = %.3f M pixel-samples, "
+                      "%.1f s wall" % (nb, rows, cw_s, W, H, spp_s, spp, samples / 1e6, wall)}
 
 
 def main():
@@ -138,7 +151,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
     # algorithmic bytes of one launch: exact work counters from the counting build (untimed)
+    note("counting pass")
     tracer.enableCounters(True)
     tracer.resetCounters()
     step()
@@ -148,6 +166,7 @@ def main():
     alg_bytes = cn.algorithmic_bytes()
     my_samples = cn.samples
 
+    note("warmup + %d timed steps" % args.steps)
     for _ in range(args.warmup):
         step()
     fence()
@@ -197,6 +216,7 @@ def main():
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
         }
         if not args.no_cpu_baseline and world == 1:
+            note("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if world > 1:

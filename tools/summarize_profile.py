@@ -16,7 +16,8 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "pt_render<0, false>"
+KERNELS = (sys.argv[3] if len(sys.argv) > 3 else "pt_prefix<false>,pt_samples_q<false>").split(",")
+KERNEL = " + ".join(KERNELS)
 
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
@@ -36,14 +37,28 @@ if os.path.isfile(bench) and os.path.getsize(bench):
     lines += ["bench.py under the tracer: value %.1f %s, kernel_ms (HIP events) %.4f, roofline.frac %.4f" %
               (b["value"], b["unit"], b["roofline"]["kernel_ms"], b["roofline"]["frac"]), ""]
 
-counters = {}
+per_kernel = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"]:
-            counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                per_kernel.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+# one trace call = one launch of each listed kernel: sum their per-launch means
+counters = {}
+for k, d in per_kernel.items():
+    for name, v in d.items():
+        counters.setdefault(name, []).append(sum(v) / len(v))
+counters = {name: [sum(v)] for name, v in counters.items()}
+if per_kernel:
+    lines += ["## PMC per kernel (mean per dispatch)", "", "| kernel | counter | mean |", "|---|---|---|"]
+    for k in KERNELS:
+        for name in sorted(per_kernel.get(k, {})):
+            v = per_kernel[k][name]
+            lines.append("| `%s` | %s | %.6g |" % (k, name, sum(v) / len(v)))
+    lines.append("")
 if counters:
-    lines += ["## PMC passes (separate `rocprofv3 --pmc ...` runs, mean per dispatch of `%s`)" % KERNEL, "",
-              "| counter | mean per launch | launches |", "|---|---|---|"]
+    lines += ["## PMC passes (separate `rocprofv3 --pmc ...` runs), summed over one launch of each of `%s`" % KERNEL,
+              "", "| counter | per trace call | |", "|---|---|---|"]
     for k in sorted(counters):
         v = counters[k]
         lines.append("| %s | %.6g | %d |" % (k, sum(v) / len(v), len(v)))
