@@ -313,9 +313,9 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
 #define RT_OPT_MAX_THREADS_PER_LAUNCH 2 /* split one render call into several kernel launches           */
 #define RT_OPT_SAMPLE_QUEUE 3           /* 1 (default): lanes pull samples from an in-wave queue as their
                                            paths end; 0: one fixed sample set per lane                  */
-#define RT_OPT_ACCEL 4                  /* sphere search: 0 brute force (the reference's loop), 1 (default)
-                                           conservative BVH for scenes of >= 64 spheres, 2 BVH always.
-                                           Same (t, index) winner in every mode                        */
+#define RT_OPT_ACCEL 4                  /* sphere / mesh search: 0 brute force (the reference's loops), 1
+                                           (default) conservative BVHs for >= 64 spheres and for meshes of
+                                           >= 32 faces, 2 sphere BVH always.  Same winner in every mode   */
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* ---- measurement --------------------------------------------------------- */

@@ -1,0 +1,192 @@
+// mesh_bvh_build.hpp — host-side builder of the per-mesh BVHs that pt_mesh_bvh.hpp walks.
+// Binned-SAH splits over face centroids, leaves of <= 4 faces; children in adjacent pairs (left at
+// an odd global index, every tree starts at an even index); per node: bounds, parent, split axis,
+// normal cone (axis, cos/sin of the half angle, widened by 1e-4 rad), smallest face index, box
+// diagonal and the smallest sin(angle between the two edges) of the subtree.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#ifndef MESH_BVH_LEAF
+#define MESH_BVH_LEAF 4  // faces per leaf (<= 7)
+#endif
+
+struct MeshBvhBuilder {
+    // inputs: the mesh's face records (3 float4 per face: A, e1, e2, n as DeviceScene::faces)
+    const float4 *rec = nullptr;
+    uint32_t n_faces = 0;
+    // outputs (appended to shared arrays)
+    std::vector<float4> *nodes = nullptr;     // 4 per node
+    std::vector<float4> *leaf_faces = nullptr;  // 3 per face
+    std::vector<uint32_t> *leaf_idx = nullptr;
+
+    std::vector<uint32_t> order;
+    std::vector<float> lo, hi, cen;  // 3 per face
+    std::vector<double> nrm;         // 3 per face (unit, or 0 for degenerate)
+    std::vector<float> qual;         // sin(phi) per face
+
+    void prepare() {
+        order.resize(n_faces);
+        lo.resize(3 * n_faces); hi.resize(3 * n_faces); cen.resize(3 * n_faces);
+        nrm.resize(3 * n_faces); qual.resize(n_faces);
+        for (uint32_t f = 0; f < n_faces; f++) {
+            order[f] = f;
+            const float4 &q0 = rec[3 * f], &q1 = rec[3 * f + 1], &q2 = rec[3 * f + 2];
+            double A[3] = {q0.x, q0.y, q0.z}, e1[3] = {q0.w, q1.x, q1.y}, e2[3] = {q1.z, q1.w, q2.x};
+            for (int k = 0; k < 3; k++) {
+                double p0 = A[k], p1 = A[k] + e1[k], p2 = A[k] + e2[k];
+                double l = std::min(p0, std::min(p1, p2)), h = std::max(p0, std::max(p1, p2));
+                // the device forms B, C as A + e in exact terms only up to rounding: pad by 2 ulp of the magnitude
+                double pad = 4e-7 * (std::fabs(l) + std::fabs(h)) + 1e-30;
+                lo[3 * f + k] = (float)(l - pad);
+                hi[3 * f + k] = (float)(h + pad);
+                cen[3 * f + k] = (float)((p0 + p1 + p2) / 3.0);
+            }
+            double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            double cl = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+            double l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+            bool ok = std::isfinite(cl) && cl > 0 && l1 > 0 && l2 > 0;
+            for (int k = 0; k < 3; k++) nrm[3 * f + k] = ok ? c[k] / cl : 0.0;
+            qual[f] = ok ? (float)(cl / (l1 * l2)) : 0.0f;
+        }
+    }
+
+    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e) {
+        float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double ax[3] = {0, 0, 0};
+        float q = INFINITY;
+        uint32_t min_face = 0xFFFFFFFFu;
+        bool degenerate = false;
+        for (uint32_t i = b; i < e; i++) {
+            uint32_t f = order[i];
+            for (int k = 0; k < 3; k++) {
+                nlo[k] = std::fmin(nlo[k], lo[3 * f + k]); nhi[k] = std::fmax(nhi[k], hi[3 * f + k]);
+                clo[k] = std::fmin(clo[k], cen[3 * f + k]); chi[k] = std::fmax(chi[k], cen[3 * f + k]);
+                ax[k] += nrm[3 * f + k];
+            }
+            q = std::fmin(q, qual[f]);
+            min_face = std::min(min_face, f);
+            if (qual[f] <= 0.0f) degenerate = true;
+        }
+        // normal cone: axis = normalised sum, half angle = largest deviation (+1e-4 rad)
+        double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        double cos_a = -1.0;
+        if (al > 1e-12 && !degenerate) {
+            for (int k = 0; k < 3; k++) ax[k] /= al;
+            cos_a = 1.0;
+            for (uint32_t i = b; i < e; i++) {
+                uint32_t f = order[i];
+                cos_a = std::min(cos_a, ax[0] * nrm[3 * f] + ax[1] * nrm[3 * f + 1] + ax[2] * nrm[3 * f + 2]);
+            }
+            double alpha = std::acos(std::max(-1.0, std::min(1.0, cos_a))) + 1e-4;
+            cos_a = alpha >= M_PI ? -1.0 : std::cos(alpha);
+        } else {
+            ax[0] = 1; ax[1] = 0; ax[2] = 0;
+        }
+        double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
+        if (cos_a <= 0.0) { cos_a = 0.0; sin_a = 1.0; }  // cone wider than a hemisphere: always "grazing"
+        if (degenerate) q = 0.0f;
+        double dx = (double)nhi[0] - nlo[0], dy = (double)nhi[1] - nlo[1], dz = (double)nhi[2] - nlo[2];
+        float diag = (float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001);
+
+        uint32_t A = parent, B;
+        if (e - b <= MESH_BVH_LEAF) {
+            uint32_t first = (uint32_t)(leaf_faces->size() / 3);
+            for (uint32_t i = b; i < e; i++) {
+                uint32_t f = order[i];
+                leaf_faces->push_back(rec[3 * f]);
+                leaf_faces->push_back(rec[3 * f + 1]);
+                leaf_faces->push_back(rec[3 * f + 2]);
+                leaf_idx->push_back(f);
+            }
+            B = 0x80000000u | ((e - b) << 28) | first;
+        } else {
+            int axis = 0;
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            uint32_t mid = b + (e - b) / 2;
+            constexpr int NB = 16;
+            double best_cost = INFINITY;
+            int best_ax = -1, best_bin = -1;
+            for (int k = 0; k < 3; k++) {
+                float ext = chi[k] - clo[k];
+                if (!(ext > 0.0f)) continue;
+                struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
+                for (auto &bn : bins) { for (int t = 0; t < 3; t++) { bn.lo[t] = INFINITY; bn.hi[t] = -INFINITY; } bn.n = 0; }
+                for (uint32_t i = b; i < e; i++) {
+                    uint32_t f = order[i];
+                    int bi = (int)((cen[3 * f + k] - clo[k]) / ext * NB);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    for (int t = 0; t < 3; t++) { bins[bi].lo[t] = std::fmin(bins[bi].lo[t], lo[3 * f + t]); bins[bi].hi[t] = std::fmax(bins[bi].hi[t], hi[3 * f + t]); }
+                    bins[bi].n++;
+                }
+                auto area = [](const float *l, const float *h) {
+                    double x = (double)h[0] - l[0], y = (double)h[1] - l[1], z = (double)h[2] - l[2];
+                    return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x);
+                };
+                double right_cost[NB];
+                float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t rn = 0;
+                for (int j = NB - 1; j > 0; j--) {
+                    for (int t = 0; t < 3; t++) { rl[t] = std::fmin(rl[t], bins[j].lo[t]); rh[t] = std::fmax(rh[t], bins[j].hi[t]); }
+                    rn += bins[j].n;
+                    right_cost[j] = rn ? area(rl, rh) * rn : INFINITY;
+                }
+                float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t ln = 0;
+                for (int j = 0; j < NB - 1; j++) {
+                    for (int t = 0; t < 3; t++) { ll[t] = std::fmin(ll[t], bins[j].lo[t]); lh[t] = std::fmax(lh[t], bins[j].hi[t]); }
+                    ln += bins[j].n;
+                    if (ln == 0 || ln == e - b) continue;
+                    double cost = area(ll, lh) * ln + right_cost[j + 1];
+                    if (cost < best_cost) { best_cost = cost; best_ax = k; best_bin = j; }
+                }
+            }
+            const float *cp = cen.data();
+            if (best_ax >= 0) {
+                axis = best_ax;
+                float ext = chi[axis] - clo[axis], base = clo[axis];
+                int bb = best_bin;
+                auto it = std::partition(order.begin() + b, order.begin() + e, [cp, axis, ext, base, bb](uint32_t f) {
+                    int bi = (int)((cp[3 * f + axis] - base) / ext * NB);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    return bi <= bb;
+                });
+                mid = (uint32_t)(it - order.begin());
+            }
+            if (best_ax < 0 || mid == b || mid == e) {
+                mid = b + (e - b) / 2;
+                std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [cp, axis](uint32_t i, uint32_t j) {
+                    return cp[3 * i + axis] < cp[3 * j + axis] || (cp[3 * i + axis] == cp[3 * j + axis] && i < j);
+                });
+            }
+            uint32_t left = (uint32_t)(nodes->size() / 4);  // odd (trees start even, pairs follow)
+            nodes->resize(nodes->size() + 8);
+            A |= (uint32_t)axis << 28;
+            B = left;
+            fill(left, me, b, mid);
+            fill(left + 1, me, mid, e);
+        }
+        float4 *nd = nodes->data() + 4 * (size_t)me;
+        nd[0] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
+        nd[1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
+        nd[2] = make_float4((float)ax[0], (float)ax[1], (float)ax[2], (float)cos_a);
+        nd[3] = make_float4((float)sin_a, 0.0f, diag, q);
+        memcpy(&nd[0].w, &A, 4);
+        memcpy(&nd[1].w, &B, 4);
+        memcpy(&nd[3].y, &min_face, 4);
+    }
+
+    // → global index of the tree's root
+    uint32_t build() {
+        prepare();
+        if ((nodes->size() / 4) & 1u) nodes->resize(nodes->size() + 4, make_float4(0, 0, 0, 0));  // even start
+        uint32_t root = (uint32_t)(nodes->size() / 4);
+        nodes->resize(nodes->size() + 4);  // the root is even, so the child pairs that follow are (odd, even)
+        fill(root, root, 0, n_faces);
+        return root;
+    }
+};

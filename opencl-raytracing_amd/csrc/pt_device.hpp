@@ -94,6 +94,11 @@ struct DeviceScene {
     // operations hitTriangle performs per test (:264-265,285); faces of mesh m start at mesh_face_base[m]
     const float4 *faces;
     const uint32_t *mesh_face_base;
+    // optional per-mesh BVHs (pt_mesh_bvh.hpp); mesh_bvh_root == nullptr or root == NONE → face scan
+    const float4 *mbvh_nodes;       // 4 float4 per node
+    const float4 *mbvh_faces;       // face records (as `faces`) in leaf order
+    const uint32_t *mbvh_face_idx;  // their face index inside the mesh
+    const uint32_t *mesh_bvh_root;  // per mesh
     // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
     const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
     const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
@@ -361,6 +366,8 @@ PT_DEV float triangle_t(const Ray &r, V3 A, V3 e1, V3 e2, float *u_out, float *v
     return t;
 }
 
+#include "pt_mesh_bvh.hpp"
+
 struct Hit {
     V3 p, n;
     float u, v;  // texture coordinates (mesh hits)
@@ -372,7 +379,8 @@ struct Hit {
 // Nearest over spheres → planes → lenses → models with strict '<' (the earlier
 // primitive keeps a tie); inside a mesh the FIRST front-facing hit in face
 // order wins, not the nearest.
-template <bool COUNT>
+// ACCEL = false compiles the BVH walks out (scenes without a BVH keep the lean kernel).
+template <bool COUNT, bool ACCEL>
 PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
     const DeviceScene &sc = c.sc;
     float best_t = RT_MAX_DISTANCE;
@@ -382,7 +390,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
 
     // spheres: through the BVH when one was built, for lanes whose direction is (nearly) unit length
     bool brute = true;
-    if (sc.bvh_node_count) {
+    if (ACCEL && sc.bvh_node_count) {
         float dd = dot(r.d, r.d);
         brute = !(fabsf(dd - 1.0f) < 0.25f);  // also catches NaN; the margin m covers any smaller deviation
         if (!brute) hit_spheres_bvh<COUNT>(sc, r, best_t, best_id, c.cn);
@@ -435,9 +443,23 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             bool found = false;
             float ft = 0.0f, fu = 0.0f, fv = 0.0f;
             uint32_t fface = 0;
+            uint32_t root = (ACCEL && sc.mesh_bvh_root) ? sc.mesh_bvh_root[mi] : PT_MESH_BVH_NONE;
+            if (ACCEL && root != PT_MESH_BVH_NONE) {
+                // smallest face index with a valid front-facing hit, through the mesh's BVH
+                uint32_t best = mesh.face_count;
+                (void)mesh_bvh_walk<0>(sc, r, root, best, ft, fu, fv);
+                found = best < mesh.face_count;
+                fface = best;
+                if (COUNT) {  // the reference's scan: faces 0..best, and the valid hits it stepped over
+                    c.cn->c[CN_T_TRI] += found ? best + 1u : mesh.face_count;
+                    float x0, x1, x2;
+                    uint32_t lim = best;
+                    c.cn->c[CN_H_TRI] += mesh_bvh_walk<1>(sc, r, root, lim, x0, x1, x2) + (found ? 1u : 0u);
+                }
+            }
             const float4 *fr = sc.faces + 3u * (size_t)sc.mesh_face_base[mi];
             float4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
-            for (uint32_t f = 0; f < mesh.face_count; f++) {
+            for (uint32_t f = 0; root == PT_MESH_BVH_NONE && f < mesh.face_count; f++) {
                 fr += 3;  // the array ends with a dummy record, so this prefetch stays in bounds
                 float4 p0 = fr[0], p1 = fr[1], p2 = fr[2];
                 if (!found) {  // a lane that has its face idles while the others keep scanning
@@ -613,12 +635,12 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
 
 // :444-486 getCol from bounce i0 on — the sky is black, a path that survives
 // DEPTH bounces returns what it has.
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 PT_DEV V3 trace_from(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t sample, uint32_t gx, uint32_t gy) {
     for (uint32_t i = i0; i < RT_DEPTH; i++) {
         Rnd rnd = fetch_rnd(c.sc.table, r.d, i + sample, gx, gy);
         Hit h;
-        if (!hit_scene<COUNT>(c, r, h)) return mk(0.0f, 0.0f, 0.0f);
+        if (!hit_scene<COUNT, ACCEL>(c, r, h)) return mk(0.0f, 0.0f, 0.0f);
         if (COUNT) c.cn->c[CN_H_BOUNCE]++;
         int type;
         float extra;
@@ -634,9 +656,9 @@ PT_DEV V3 trace_from(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t sample, 
     return out;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 PT_DEV V3 radiance(const Ctx &c, Ray r, uint32_t sample, uint32_t gx, uint32_t gy) {
-    return trace_from<COUNT>(c, r, mk(1.0f, 1.0f, 1.0f), 0, sample, gx, gy);
+    return trace_from<COUNT, ACCEL>(c, r, mk(1.0f, 1.0f, 1.0f), 0, sample, gx, gy);
 }
 
 // :129-139, :500-505 — no pixel jitter
@@ -665,14 +687,14 @@ struct PixelRec {        // 80 bytes
 };
 enum { REC_FINAL = 0, REC_VERTEX = 1 };
 
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
     PixelRec rec;
     V3 out = mk(1.0f, 1.0f, 1.0f);
     rec.p_kind = rec.n_extra = rec.d = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < RT_DEPTH; i++) {
         Hit h;
-        if (!hit_scene<COUNT>(c, r, h)) {
+        if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
             out = mk(0.0f, 0.0f, 0.0f);
             break;
         }
@@ -709,7 +731,7 @@ PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
 }
 
 // radiance of one sample continuing from its pixel's record
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, uint32_t gx, uint32_t gy) {
     uint32_t bits = __float_as_uint(rec.p_kind.w);
     if ((bits & 0xFFu) == REC_FINAL) return xyz(rec.out);
@@ -727,7 +749,7 @@ PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, 
     V3 out = xyz(rec.out);
     Rnd rnd = fetch_rnd(c.sc.table, r.d, depth + sample, gx, gy);
     scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), rnd);
-    return trace_from<COUNT>(c, r, out, depth + 1, sample, gx, gy);
+    return trace_from<COUNT, ACCEL>(c, r, out, depth + 1, sample, gx, gy);
 }
 
 }  // namespace pt

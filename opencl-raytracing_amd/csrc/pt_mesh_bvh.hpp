@@ -1,0 +1,130 @@
+// pt_mesh_bvh.hpp — conservative BVH for the reference's mesh rule (device side).
+//
+// hitMeshOut (kernels/raytracer.cl:291-303) scans the faces of a mesh in index order
+// and returns the FIRST face whose hitTriangle succeeds and whose normal faces the
+// ray — not the nearest.  The same answer is "the smallest face index among valid
+// front-facing hits", which a spatial hierarchy can find without scanning 50 000
+// faces — provided it never drops a face the reference would have accepted.
+//
+// Why culling is safe (DESIGN.md "mesh BVH").  hitTriangle is Möller–Trumbore in
+// binary32 (:257-289); it is invariant to the length of the direction.  Let X be the
+// exact intersection of the ray's LINE with the face's plane.  Forward error analysis
+// of (a, u, v) gives: if the computed (u, v) pass the reference's tests, X lies within
+//     rho = 1.1e-6 · (|s| + |e1| + |e2|) / (sin(phi) · |cos(theta)|)
+// of the triangle (u = 2^-24; s = origin − A; phi = angle between the edges; theta =
+// angle between the direction and the face normal), as long as |cos(theta)| is not at
+// the noise level.  So a node may be skipped when the line misses its box inflated by
+// rho evaluated with the node's worst case: |s| <= dfar (largest distance origin → box),
+// |e| <= box diagonal, sin(phi) >= q (smallest over the subtree), |cos(theta)| >= the
+// minimum over the subtree's NORMAL CONE — and it is never skipped (only index-pruned)
+// when that minimum is below TAU (the ray may graze some face of the subtree: the
+// computed barycentrics of such a face are unreliable far from it).  K below carries a
+// 4x safety factor.  Candidates are tested with the very same triangle_t() and the
+// very same precomputed normal as the brute-force scan, so a visited face gives the
+// reference's verdict bit for bit.
+//
+// Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, diagonal, q)
+//   A = parent | split_axis << 28;  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
+// Stackless ordered traversal as in hit_spheres_bvh (children adjacent, left child odd).
+// (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
+#pragma once
+
+#define PT_MESH_BVH_NONE 0xFFFFFFFFu
+#define PT_MESH_TAU 2.0e-3f
+#define PT_MESH_K 5.0e-6f
+
+// MODE 0: search — smallest face index < best_face with a valid front-facing hit.
+// MODE 1: count  — number of faces with index < best_face whose hitTriangle succeeds (any
+//                  facing): the reference's H_tri counter needs the back-facing hits it
+//                  stepped over before its first front-facing one.
+template <int MODE>
+PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
+                              float &fu, float &fv) {
+    float inv_len = 1.0f / sqrtf(dot(r.d, r.d));
+    V3 dh = r.d * inv_len;
+    V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+    uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
+    uint32_t hits = 0;
+
+    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
+    uint32_t cur = root;
+    int state = FROM_PARENT;
+    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; guard++) {  // every node is entered at most 3 times
+        const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
+        float4 a = nd[0], b = nd[1];
+        uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
+        uint32_t parent = A & 0x0FFFFFFFu;
+        uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
+        if (state == FROM_CHILD) {
+            if (cur == root) break;
+            const float4 *pn = sc.mbvh_nodes + 4 * (size_t)parent;
+            uint32_t pleft = __float_as_uint(pn[1].w), paxis = (__float_as_uint(pn[0].w) >> 28) & 3u;
+            uint32_t pnear = pleft + ((far_first >> paxis) & 1u);
+            if (cur == pnear) {
+                cur = sibling;
+                state = FROM_SIBLING;
+            } else {
+                cur = parent;
+            }
+            continue;
+        }
+        float4 cn = nd[2], ex = nd[3];
+        bool miss = __float_as_uint(ex.y) >= best_face;  // every face below has a larger index than the best
+        if (!miss) {
+            // smallest |cos(theta)| over the subtree's normal cone
+            float x = dot(dh, xyz(cn));
+            float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
+            float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
+            if (cosmin > PT_MESH_TAU && ex.w > 1.0e-6f) {  // no face of the subtree can be grazed: box test
+                float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
+                float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
+                float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
+                float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;
+                float m = PT_MESH_K * (dfar + ex.z) / (ex.w * cosmin) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
+                float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
+                float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
+                t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
+                tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+                t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
+                tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+                // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
+                miss = tmin > tmax + fabsf(tmax) * 1.0e-5f + 1.0e-4f || tmax < -(m + 1.0f) ||
+                       tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
+            }
+        }
+        bool leaf = (B & 0x80000000u) != 0;
+        if (!miss && leaf) {
+            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                uint32_t idx = sc.mbvh_face_idx[first + k];
+                if (idx >= best_face) continue;
+                const float4 *fq = sc.mbvh_faces + 3 * (size_t)(first + k);
+                float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
+                float u, v;
+                float t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
+                if (t > 0.0f) {
+                    if (MODE == 1) hits++;
+                    else if (dot(mk(q2.y, q2.z, q2.w), r.d) < 0.0f) {
+                        best_face = idx;
+                        ft = t; fu = u; fv = v;
+                    }
+                }
+            }
+        }
+        if (!miss && !leaf) {
+            uint32_t axis = (A >> 28) & 3u;
+            cur = B + ((far_first >> axis) & 1u);
+            state = FROM_PARENT;
+        } else if (cur == root) {
+            break;
+        } else if (state == FROM_PARENT) {
+            cur = sibling;
+            state = FROM_SIBLING;
+        } else {
+            cur = parent;
+            state = FROM_CHILD;
+        }
+    }
+    return hits;
+}

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "pt_device.hpp"
+#include "mesh_bvh_build.hpp"
 
 using namespace pt;
 
@@ -95,7 +96,7 @@ PT_DEV void accumulate(float4 *__restrict__ accum, size_t pix, V3 sum, uint32_t 
 //   MODE_ACCUM   accum += (sum, count)                      (rt_render_spp, prefix sharing off)
 //   MODE_TRACE   image = sqrt(radiance(sample first))        (`trace`,  raytracer.cl:496-510)
 //   MODE_RETRACE image = sqrt(mix(new, image², k/(k+1)))     (`retrace`, raytracer.cl:512-532)
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp, float4 *__restrict__ accum,
                                                  float4 *__restrict__ image, unsigned long long *counters) {
     __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp,
         Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
-            sum = sum + radiance<COUNT>(c, r0, s, x, y);
+            sum = sum + radiance<COUNT, ACCEL>(c, r0, s, x, y);
         }
     }
     sum = group_sum(sum, g);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp,
 // glass chains) is finished here: all its samples are equal, and their sum in the
 // order of stage 2 (k sequential adds per lane, then log2(g) doublings) is
 // computed in closed form.  Other pixels are appended to the live list.
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp, PixelRec *__restrict__ recs,
                                                  uint32_t *__restrict__ live, uint32_t *__restrict__ live_count,
                                                  float4 *__restrict__ accum, unsigned long long *counters) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     bool is_live = false;
     if (valid) {
         Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
-        PixelRec rec = trace_prefix<COUNT>(c, r0, x, y);
+        PixelRec rec = trace_prefix<COUNT, ACCEL>(c, r0, x, y);
         uint32_t g = 1u << fp.group_log2;
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         if (final_px && (fp.count & (g - 1u)) == 0) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
 
 // Fused path, stage 2: one group of g lanes per LIVE pixel; each lane continues
 // its samples from the pixel's record.  Same summation order as pt_render.
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                   const uint32_t *__restrict__ live,
                                                   const uint32_t *__restrict__ live_count,
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
-            sum = sum + radiance_from_rec<COUNT>(c, rec, s, x, y);
+            sum = sum + radiance_from_rec<COUNT, ACCEL>(c, rec, s, x, y);
         }
         (void)final_px;
     }
@@ -244,7 +245,7 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 5  // waves per SIMD the register allocator must leave room for (A/B: 4 → 3.15 ms, 5 → 2.91, 6 → 3.39)
 #endif
-template <bool COUNT>
+template <bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
             if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
             V3 res;
             bool done = false;
-            if (!hit_scene<COUNT>(c, r, h)) {
+            if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
                 res = mk(0.0f, 0.0f, 0.0f);
                 done = true;
             } else {
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
 }
 
 // parity probe: one work-item per listed pixel-sample
+template <bool ACCEL>
 __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
                                                 const uint32_t *__restrict__ ys, const uint32_t *__restrict__ ss,
                                                 uint32_t n, float *__restrict__ out) {
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, 
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
-    V3 col = radiance<false>(c, r0, ss[i], xs[i], ys[i]);
+    V3 col = radiance<false, ACCEL>(c, r0, ss[i], xs[i], ys[i]);
     out[3 * i] = col.x;
     out[3 * i + 1] = col.y;
     out[3 * i + 2] = col.z;
@@ -492,6 +494,7 @@ void make_table(uint64_t seed, float *out) {
 }
 
 #define ACCEL_MIN_SPHERES 64
+#define MESH_BVH_MIN_FACES 32
 
 // Sphere BVH (see hit_spheres_bvh): binned surface-area-heuristic splits (16 bins per axis over the
 // centroids; median split when no bin boundary separates them), leaves of <= 4 spheres; children
@@ -658,6 +661,9 @@ struct rt_context {
     uint32_t sphere_batches = 0;
     DevBuf<float4> faces;
     DevBuf<uint32_t> mesh_face_base;
+    DevBuf<float4> mbvh_nodes, mbvh_faces;
+    DevBuf<uint32_t> mbvh_face_idx, mesh_bvh_root;
+    bool have_mesh_bvh = false;
     DevBuf<float4> bvh_nodes, bvh_sph;
     DevBuf<uint32_t> bvh_idx;
     uint32_t bvh_node_count = 0;
@@ -745,6 +751,10 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.material_count = (uint32_t)ctx->materials.n;
     s.faces = ctx->faces.p;
     s.mesh_face_base = ctx->mesh_face_base.p;
+    s.mbvh_nodes = ctx->mbvh_nodes.p;
+    s.mbvh_faces = ctx->mbvh_faces.p;
+    s.mbvh_face_idx = ctx->mbvh_face_idx.p;
+    s.mesh_bvh_root = (ctx->have_mesh_bvh && ctx->accel != 0) ? ctx->mesh_bvh_root.p : nullptr;
     bool use_bvh = ctx->bvh_node_count && (ctx->accel == 2 || (ctx->accel == 1 && ctx->spheres.n >= ACCEL_MIN_SPHERES));
     s.bvh_nodes = ctx->bvh_nodes.p;
     s.bvh_sph = ctx->bvh_sph.p;
@@ -815,6 +825,14 @@ int check_ready(rt_context *ctx, const float *cam) {
     return RT_OK;
 }
 
+// kernels come in (COUNT, ACCEL) instantiations; scenes without any BVH run the ACCEL = false ones
+inline bool scene_has_accel(const DeviceScene &sc) { return sc.bvh_node_count != 0 || sc.mesh_bvh_root != nullptr; }
+#define PT_DISPATCH(count_on, accel_on, CALL)                           \
+    do {                                                                \
+        if (count_on) { if (accel_on) CALL(true, true); else CALL(true, false); }   \
+        else { if (accel_on) CALL(false, true); else CALL(false, false); }          \
+    } while (0)
+
 int ensure_slots(rt_context *ctx, size_t slots) {
     if (slots <= ctx->slot_capacity) return RT_OK;
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
@@ -846,12 +864,10 @@ int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t
         fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
         uint64_t threads = (uint64_t)(fp.slot_end - fp.slot_begin) << glog2;
         dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-        if (ctx->count_enabled)
-            hipLaunchKernelGGL((pt_render<MODE, true>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum, ctx->d_image,
-                               ctx->d_counters);
-        else
-            hipLaunchKernelGGL((pt_render<MODE, false>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum,
-                               ctx->d_image, ctx->d_counters);
+#define PT_CALL(C, A) \
+    hipLaunchKernelGGL((pt_render<MODE, C, A>), grid, block, 0, ctx->stream, sc, fp, ctx->d_accum, ctx->d_image, ctx->d_counters)
+        PT_DISPATCH(ctx->count_enabled, scene_has_accel(sc), PT_CALL);
+#undef PT_CALL
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));
@@ -884,25 +900,19 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
         size_t lds_q = 2 * PT_LDS_MATERIALS * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
-        if (ctx->count_enabled) {
-            hipLaunchKernelGGL((pt_prefix<true>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
-                               live_count, ctx->d_accum, ctx->d_counters);
-            if (queue)
-                hipLaunchKernelGGL((pt_samples_q<true>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
-                                   live_count, ctx->d_accum, ctx->d_counters, ppw);
-            else
-                hipLaunchKernelGGL((pt_samples<true>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
-                                   live_count, ctx->d_accum, ctx->d_counters);
-        } else {
-            hipLaunchKernelGGL((pt_prefix<false>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
-                               live_count, ctx->d_accum, ctx->d_counters);
-            if (queue)
-                hipLaunchKernelGGL((pt_samples_q<false>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs,
-                                   ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw);
-            else
-                hipLaunchKernelGGL((pt_samples<false>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,
-                                   live_count, ctx->d_accum, ctx->d_counters);
-        }
+#define PT_CALL_PREFIX(C, A) \
+    hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
+#define PT_CALL_QUEUE(C, A) \
+    hipLaunchKernelGGL((pt_samples_q<C, A>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+#define PT_CALL_FIXED(C, A) \
+    hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
+        bool accel_on = scene_has_accel(sc);
+        PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
+        if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
+        else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
+#undef PT_CALL_PREFIX
+#undef PT_CALL_QUEUE
+#undef PT_CALL_FIXED
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));
@@ -994,6 +1004,10 @@ void rt_destroy(rt_context *ctx) {
     ctx->sph4.release();
     ctx->faces.release();
     ctx->mesh_face_base.release();
+    ctx->mbvh_nodes.release();
+    ctx->mbvh_faces.release();
+    ctx->mbvh_face_idx.release();
+    ctx->mesh_bvh_root.release();
     ctx->bvh_nodes.release();
     ctx->bvh_sph.release();
     ctx->bvh_idx.release();
@@ -1115,6 +1129,28 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         }
         HIP_TRY(ctx, ctx->faces.upload(fr.data(), fr.size()));
         HIP_TRY(ctx, ctx->mesh_face_base.upload(base.data(), d->mesh_count));
+        // per-mesh BVHs for the "first front-facing hit in face order" rule (pt_mesh_bvh.hpp)
+        std::vector<float4> nodes, lfaces;
+        std::vector<uint32_t> lidx, roots(d->mesh_count ? d->mesh_count : 1, PT_MESH_BVH_NONE);
+        ctx->have_mesh_bvh = false;
+        for (uint32_t m = 0; m < d->mesh_count; m++) {
+            if (d->meshes[m].face_count < MESH_BVH_MIN_FACES || d->meshes[m].face_count >= (1u << 27)) continue;
+            MeshBvhBuilder mb;
+            mb.rec = &fr[3 * (size_t)base[m]];
+            mb.n_faces = d->meshes[m].face_count;
+            mb.nodes = &nodes;
+            mb.leaf_faces = &lfaces;
+            mb.leaf_idx = &lidx;
+            roots[m] = mb.build();
+            ctx->have_mesh_bvh = true;
+        }
+        if (nodes.size() / 4 >= (1u << 28) || lidx.size() >= (1u << 28)) ctx->have_mesh_bvh = false;
+        if (nodes.empty()) nodes.resize(4, make_float4(0, 0, 0, 0));
+        if (lfaces.empty()) lfaces.resize(3, make_float4(0, 0, 0, 0));
+        HIP_TRY(ctx, ctx->mbvh_nodes.upload(nodes.data(), nodes.size()));
+        HIP_TRY(ctx, ctx->mbvh_faces.upload(lfaces.data(), lfaces.size()));
+        HIP_TRY(ctx, ctx->mbvh_face_idx.upload(lidx.data(), lidx.size()));
+        HIP_TRY(ctx, ctx->mesh_bvh_root.upload(roots.data(), d->mesh_count));
     }
     ctx->bvh_node_count = 0;
     if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {
@@ -1308,8 +1344,13 @@ int rt_trace_samples(rt_context *ctx, const float camera[12], const uint32_t *x,
     if (e == hipSuccess) e = hipMemcpyAsync(d_in + 2 * n, sample, n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         FrameParams fp = frame_params(ctx, camera, 0, 1, 0);
-        hipLaunchKernelGGL(pt_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, device_scene(ctx), fp,
-                           d_in, d_in + n, d_in + 2 * n, (uint32_t)n, d_out);
+        DeviceScene sc = device_scene(ctx);
+        if (scene_has_accel(sc))
+            hipLaunchKernelGGL(pt_probe<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, fp, d_in,
+                               d_in + n, d_in + 2 * n, (uint32_t)n, d_out);
+        else
+            hipLaunchKernelGGL(pt_probe<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, fp, d_in,
+                               d_in + n, d_in + 2 * n, (uint32_t)n, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_rgb, d_out, 3 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);

@@ -279,3 +279,59 @@ def test_sphere_bvh_adversarial_scene(oracle, table):
     exp, _ = oracle.samples(s, cam, table, w, h, xs, ys, ss)
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
     t.close()
+
+
+def _mesh_scene(segments, rings, camera_inside=False):
+    """Two uv-sphere meshes (one dielectric, one textured, in one model each) that overlap, a mirror
+    sphere, a plane and a light: rays enter, leave, graze and miss meshes of 2·segments·(rings−1) faces."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.3)   # 0
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.8, 0.8, 0.8), 1)  # 1
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)          # 2
+    s.addMaterial(rt._abi.T_TEXTURED, (1, 1, 1), 1)       # 3
+    s.addMaterial(rt._abi.T_REFLECTIVE, (1, 1, 1), 0.9)   # 4
+    pos, uv, idx = rt.workloads.uv_sphere(segments, rings, radius=2.5, centre=(0.0, 2.0, 0.0))
+    s.addMesh(pos, uv, idx)
+    s.addModel(1, 0)
+    pos, uv, idx = rt.workloads.uv_sphere(segments // 2 + 3, rings // 2 + 3, radius=1.7, centre=(2.6, 2.6, 0.8))
+    s.addMesh(pos, uv, idx, texture_ID=0)
+    s.addModel(1, 3)
+    s.setTextures(rt.workloads.checker_texture(32, 4))
+    s.addSphere((1, -200, 0), 100, 2)
+    s.addSphere((-4.5, 3.5, 1.0), 1.5, 4)
+    s.addPlane((0, 5, 0), (0, 1, 0), 1)
+    cam = rt.Camera(60, 16 / 9, (0.2, 2.1, 0.3) if camera_inside else (-7, 0, -7), 45.0, 8.0).transferData()
+    return s, cam
+
+
+@pytest.mark.parametrize("segments,rings,inside", [(24, 16, False), (100, 60, False), (60, 40, True)])
+def test_mesh_bvh_changes_no_bit(segments, rings, inside, oracle, table):
+    """RT_OPT_ACCEL for meshes: the conservative per-mesh BVH (first front-facing hit in face order)
+    against the reference's face-by-face scan — identical accumulators, compat images, probes and
+    counters; and the probes against the oracle."""
+    s, cam = _mesh_scene(segments, rings, inside)
+    w, h = 128, 72
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    rng = np.random.RandomState(17)
+    n = 3000
+    xs, ys, ss = rng.randint(0, w, n), rng.randint(0, h, n), rng.randint(0, 2000, n)
+    out = []
+    for accel in (0, 1):
+        t.setOption(t.OPT_ACCEL, accel)
+        t.enableCounters(True)
+        t.resetCounters()
+        t.clear()
+        t.renderSamples(cam, 0, 8)
+        lin = t.readLinear()
+        cn = t.counters().as_dict()
+        t.enableCounters(False)
+        t.render(cam)
+        t.renderAgain(cam)
+        out.append((lin, cn, t.transferImage(), t.traceSamples(cam, xs, ys, ss)))
+    for k in (0, 2, 3):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    assert out[0][1] == out[1][1]
+    exp, _ = oracle.samples(s, cam, table, w, h, xs[:600], ys[:600], ss[:600])
+    assert np.array_equal(out[1][3][:600].view(np.uint32), exp.view(np.uint32))
+    assert (out[1][0][..., :3].sum(-1) > 0).mean() > 0.2
+    t.close()
