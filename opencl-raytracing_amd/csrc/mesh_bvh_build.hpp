@@ -1,8 +1,8 @@
 // mesh_bvh_build.hpp — host-side builder of the per-mesh BVHs that pt_mesh_bvh.hpp walks.
 // Binned-SAH splits over face centroids, leaves of <= 4 faces; children in adjacent pairs (left at
 // an odd global index, every tree starts at an even index); per node: bounds, parent, split axis,
-// normal cone (axis, cos/sin of the half angle, widened by 1e-4 rad), smallest face index, box
-// diagonal and the smallest sin(angle between the two edges) of the subtree.
+// normal cone (axis, cos/sin of the half angle, widened by 1e-4 rad), smallest face index, longest
+// edge and the smallest sin(angle between the two edges) of the subtree.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -10,7 +10,7 @@
 #include <vector>
 
 #ifndef MESH_BVH_LEAF
-#define MESH_BVH_LEAF 4  // faces per leaf (<= 7)
+#define MESH_BVH_LEAF 2  // faces per leaf (<= 7); A/B on C5: 1 → 249 ms, 2 → 227 ms, 4 → 280 ms
 #endif
 
 struct MeshBvhBuilder {
@@ -26,11 +26,12 @@ struct MeshBvhBuilder {
     std::vector<float> lo, hi, cen;  // 3 per face
     std::vector<double> nrm;         // 3 per face (unit, or 0 for degenerate)
     std::vector<float> qual;         // sin(phi) per face
+    std::vector<float> elen;         // longest of |e1|, |e2|, |e2 - e1| per face
 
     void prepare() {
         order.resize(n_faces);
         lo.resize(3 * n_faces); hi.resize(3 * n_faces); cen.resize(3 * n_faces);
-        nrm.resize(3 * n_faces); qual.resize(n_faces);
+        nrm.resize(3 * n_faces); qual.resize(n_faces); elen.resize(n_faces);
         for (uint32_t f = 0; f < n_faces; f++) {
             order[f] = f;
             const float4 &q0 = rec[3 * f], &q1 = rec[3 * f + 1], &q2 = rec[3 * f + 2];
@@ -51,6 +52,9 @@ struct MeshBvhBuilder {
             bool ok = std::isfinite(cl) && cl > 0 && l1 > 0 && l2 > 0;
             for (int k = 0; k < 3; k++) nrm[3 * f + k] = ok ? c[k] / cl : 0.0;
             qual[f] = ok ? (float)(cl / (l1 * l2)) : 0.0f;
+            double d3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+            double l3 = std::sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+            elen[f] = (float)(std::max(l1, std::max(l2, l3)) * 1.0001);
         }
     }
 
@@ -58,7 +62,7 @@ struct MeshBvhBuilder {
         float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         double ax[3] = {0, 0, 0};
-        float q = INFINITY;
+        float q = INFINITY, emax = 0.0f;
         uint32_t min_face = 0xFFFFFFFFu;
         bool degenerate = false;
         for (uint32_t i = b; i < e; i++) {
@@ -69,6 +73,7 @@ struct MeshBvhBuilder {
                 ax[k] += nrm[3 * f + k];
             }
             q = std::fmin(q, qual[f]);
+            emax = std::fmax(emax, elen[f]);
             min_face = std::min(min_face, f);
             if (qual[f] <= 0.0f) degenerate = true;
         }
@@ -90,8 +95,7 @@ struct MeshBvhBuilder {
         double sin_a = std::sqrt(std::max(0.0, 1.0 - cos_a * cos_a));
         if (cos_a <= 0.0) { cos_a = 0.0; sin_a = 1.0; }  // cone wider than a hemisphere: always "grazing"
         if (degenerate) q = 0.0f;
-        double dx = (double)nhi[0] - nlo[0], dy = (double)nhi[1] - nlo[1], dz = (double)nhi[2] - nlo[2];
-        float diag = (float)(std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001);
+        if (!std::isfinite(emax)) { emax = INFINITY; q = 0.0f; }
 
         uint32_t A = parent, B;
         if (e - b <= MESH_BVH_LEAF) {
@@ -174,7 +178,7 @@ struct MeshBvhBuilder {
         nd[0] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
         nd[1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
         nd[2] = make_float4((float)ax[0], (float)ax[1], (float)ax[2], (float)cos_a);
-        nd[3] = make_float4((float)sin_a, 0.0f, diag, q);
+        nd[3] = make_float4((float)sin_a, 0.0f, emax, q);
         memcpy(&nd[0].w, &A, 4);
         memcpy(&nd[1].w, &B, 4);
         memcpy(&nd[3].y, &min_face, 4);

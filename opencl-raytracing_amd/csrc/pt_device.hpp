@@ -447,7 +447,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             if (ACCEL && root != PT_MESH_BVH_NONE) {
                 // smallest face index with a valid front-facing hit, through the mesh's BVH
                 uint32_t best = mesh.face_count;
-                (void)mesh_bvh_walk<0>(sc, r, root, best, ft, fu, fv);
+                (void)mesh_bvh_walk<0>(sc, r, root, best, ft, fu, fv, COUNT ? c.cn : nullptr);
                 found = best < mesh.face_count;
                 fface = best;
                 if (COUNT) {  // the reference's scan: faces 0..best, and the valid hits it stepped over

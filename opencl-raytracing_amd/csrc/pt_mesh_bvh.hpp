@@ -18,12 +18,16 @@
 // |e| <= box diagonal, sin(phi) >= q (smallest over the subtree), |cos(theta)| >= the
 // minimum over the subtree's NORMAL CONE — and it is never skipped (only index-pruned)
 // when that minimum is below TAU (the ray may graze some face of the subtree: the
-// computed barycentrics of such a face are unreliable far from it).  K below carries a
-// 4x safety factor.  Candidates are tested with the very same triangle_t() and the
+// computed barycentrics of such a face are unreliable far from it) — except through the
+// cap that the reference's own rejection |a| < TRIANGLE_EPSILON provides: an accepted face
+// has |a_computed| >= 1e-7, and for edges short enough that the rounding error of a stays
+// below half of that (emax² <= 0.04/|d|), |a| >= 0.5e-7 bounds the displacement by
+// rho_cap = 66·|d|·(|s| + 2·emax)·emax² whatever the angle.  K below carries a 4x safety
+// factor, the cap 1.5x.  Candidates are tested with the very same triangle_t() and the
 // very same precomputed normal as the brute-force scan, so a visited face gives the
 // reference's verdict bit for bit.
 //
-// Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, diagonal, q)
+// Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
 //   A = parent | split_axis << 28;  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
 // Stackless ordered traversal as in hit_spheres_bvh (children adjacent, left child odd).
 // (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
@@ -39,8 +43,9 @@
 //                  stepped over before its first front-facing one.
 template <int MODE>
 PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
-                              float &fu, float &fv) {
-    float inv_len = 1.0f / sqrtf(dot(r.d, r.d));
+                              float &fu, float &fv, LaneCounters *dbg = nullptr) {
+    float dlen = sqrtf(dot(r.d, r.d));
+    float inv_len = 1.0f / dlen;
     V3 dh = r.d * inv_len;
     V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
@@ -70,18 +75,24 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
             continue;
         }
         float4 cn = nd[2], ex = nd[3];
+        if (dbg) dbg->c[CN_DBG_BVH_NODES]++;
         bool miss = __float_as_uint(ex.y) >= best_face;  // every face below has a larger index than the best
         if (!miss) {
             // smallest |cos(theta)| over the subtree's normal cone
             float x = dot(dh, xyz(cn));
             float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
             float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
-            if (cosmin > PT_MESH_TAU && ex.w > 1.0e-6f) {  // no face of the subtree can be grazed: box test
+            bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-6f;    // no face of the subtree can be grazed
+            bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
+            if (steep || capped) {
                 float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
                 float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
                 float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
                 float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;
-                float m = PT_MESH_K * (dfar + ex.z) / (ex.w * cosmin) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
+                float reach = dfar + 2.0f * ex.z;
+                float m_steep = steep ? PT_MESH_K * reach / (ex.w * cosmin) : INFINITY;
+                float m_cap = capped ? 66.0f * dlen * reach * ex.z * ex.z : INFINITY;
+                float m = fminf(m_steep, m_cap) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
                 float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
                 float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
                 t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
@@ -101,6 +112,7 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
                 if (idx >= best_face) continue;
                 const float4 *fq = sc.mbvh_faces + 3 * (size_t)(first + k);
                 float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
+                if (dbg) dbg->c[CN_DBG_BVH_TESTS]++;
                 float u, v;
                 float t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
                 if (t > 0.0f) {
