@@ -68,6 +68,11 @@ PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 #define PT_BEHIND_SKIP 1   // skip the square root for spheres behind the ray origin
 #endif
 
+#ifndef PT_LDS_SPHERES
+#define PT_LDS_SPHERES 0   // A/B switch: 1 = the brute-force sphere loop reads an LDS copy of the spheres
+#endif                     // (ds_read_b128 broadcast) instead of scalar loads; measured slower, DESIGN.md §5
+#define PT_LDS_SPHERE_CAP 256
+
 #define PT_LDS_MATERIALS 64  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
 #define PT_SPHERE_BATCH 4
 
@@ -126,6 +131,7 @@ struct Ctx {
     const DeviceScene &sc;
     const float4 *lmat;  // LDS: [2i] = (r,g,b,extra), [2i+1].x = type bits; nullptr → read global
     LaneCounters *cn;
+    const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
 };
 
 // ---- materials in LDS ----------------------------------------------------------
@@ -140,6 +146,16 @@ PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
     __syncthreads();
     return lds;
 }
+// PT_LDS_SPHERES experiment: stage the sphere test data of small scenes (after stage_materials' barrier
+// has been passed by every thread; contains its own barrier)
+PT_DEV const float4 *stage_spheres(const DeviceScene &sc, float4 *lds) {
+    uint32_t n = (sc.sphere_batches + 1u) * PT_SPHERE_BATCH;
+    if (!PT_LDS_SPHERES || n > PT_LDS_SPHERE_CAP) return nullptr;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[i] = sc.sph4[i];
+    __syncthreads();
+    return lds;
+}
+
 PT_DEV void load_material(const Ctx &c, uint32_t id, int &type, float &extra, V3 &col) {
     if (c.lmat) {
         float4 a = c.lmat[2 * id];
@@ -398,7 +414,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
     // brute force: wave-uniform index → scalar loads; a batch of 4 in flight while 4 are tested
     if (COUNT && brute) c.cn->c[CN_DBG_BVH_TESTS] += sc.sphere_count;
     if (brute && sc.sphere_batches) {
-        const float4 *sp = sc.sph4;
+        const float4 *sp = (PT_LDS_SPHERES && c.lsph) ? c.lsph : sc.sph4;
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
         for (uint32_t b = 0; b < sc.sphere_batches; b++) {
             sp += PT_SPHERE_BATCH;  // the array ends with one dummy batch, so this prefetch is always in bounds

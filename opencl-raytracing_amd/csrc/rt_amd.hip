@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+#if PT_LDS_SPHERES
+    __shared__ float4 s_sph[PT_LDS_SPHERE_CAP];
+    c.lsph = stage_spheres(sc, s_sph);
+#endif
 
     uint32_t slot = fp.slot_begin + blockIdx.x * 256u + threadIdx.x;
     uint32_t x = 0, y = 0;
@@ -256,9 +260,12 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+#if PT_LDS_SPHERES
+    c.lsph = stage_spheres(sc, s_dyn + 2 * PT_LDS_MATERIALS);
+#endif
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    char *wave_lds = reinterpret_cast<char *>(s_dyn + 2 * PT_LDS_MATERIALS) +
+    char *wave_lds = reinterpret_cast<char *>(s_dyn + 2 * PT_LDS_MATERIALS + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
@@ -899,7 +906,8 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         ppw = ppw < 1 ? 1 : (ppw > QUEUE_MAX_PIXELS ? QUEUE_MAX_PIXELS : ppw);
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
-        size_t lds_q = 2 * PT_LDS_MATERIALS * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
+        size_t lds_q = (2 * PT_LDS_MATERIALS + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) * sizeof(float4) +
+                       4 * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
 #define PT_CALL_QUEUE(C, A) \
