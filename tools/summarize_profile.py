@@ -16,7 +16,7 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNELS = (sys.argv[3] if len(sys.argv) > 3 else "pt_prefix<false>,pt_samples_q<false>").split(",")
+KERNELS = (sys.argv[3] if len(sys.argv) > 3 else "pt_prefix<false, false>;pt_samples_q<false, false>").split(";")
 KERNEL = " + ".join(KERNELS)
 
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
