@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N>1: gather of packed tiles (default) or full-frame RCCL reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg")
     args = ap.parse_args()
 
@@ -215,6 +216,19 @@ def main():
                          "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3)},
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
         }
+        if world == 1 and not args.no_parity_check:
+            # untimed sanity leg: the configuration just measured computes the reference's radiance —
+            # probes of the frame against the oracle (checker only, never the thing measured)
+            note("parity probes")
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from oracle import Oracle
+            rng = np.random.RandomState(1)
+            n = 64 if args.workload in ("c4", "c5") else 2000
+            xs, ys, ss = rng.randint(0, wl.width, n), rng.randint(0, wl.height, n), rng.randint(0, spp, n)
+            got = tracer.traceSamples(wl.camera, xs, ys, ss)
+            exp, _ = Oracle().samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
+            same = int((got.view(np.uint32) == exp.view(np.uint32)).all(axis=1).sum())
+            out["parity"] = {"probes": n, "bit_exact": same, "checker": "oracle/pt_oracle.c"}
         if not args.no_cpu_baseline and world == 1:
             note("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget)

@@ -791,29 +791,32 @@ DeviceScene device_scene(const rt_context *ctx) {
 struct Shard {
     uint32_t tiles_x, tiles_total, owned_tiles, slots;
 };
-Shard shard_of(const rt_context *ctx) {
+Shard shard_of(const rt_context *ctx, int rank, int world) {
     Shard s;
     uint32_t tw = 1u << ctx->tile_w_log2, th = 1u << ctx->tile_h_log2;
     s.tiles_x = (ctx->width + tw - 1) / tw;
     uint32_t tiles_y = (ctx->height + th - 1) / th;
     s.tiles_total = s.tiles_x * tiles_y;
-    s.owned_tiles = s.tiles_total > (uint32_t)ctx->rank ? (s.tiles_total - ctx->rank + ctx->world - 1) / ctx->world : 0;
+    s.owned_tiles = s.tiles_total > (uint32_t)rank ? (s.tiles_total - rank + world - 1) / world : 0;
     s.slots = s.owned_tiles * tw * th;
     return s;
 }
 
-FrameParams frame_params(const rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2) {
+// frame parameters for the shard (rank of world); rank < 0 → the context's own shard
+FrameParams frame_params(const rt_context *ctx, const float cam[12], uint32_t first, uint32_t count, uint32_t glog2,
+                         int rank = -1, int world = 1) {
+    if (rank < 0) { rank = ctx->rank; world = ctx->world; }
     FrameParams fp;
     memcpy(fp.cam, cam, sizeof fp.cam);
-    Shard sh = shard_of(ctx);
+    Shard sh = shard_of(ctx, rank, world);
     fp.w = ctx->width;
     fp.h = ctx->height;
     fp.tile_w_log2 = ctx->tile_w_log2;
     fp.tile_h_log2 = ctx->tile_h_log2;
     fp.tiles_x = sh.tiles_x;
     fp.tiles_total = sh.tiles_total;
-    fp.rank = ctx->rank;
-    fp.world = ctx->world;
+    fp.rank = (uint32_t)rank;
+    fp.world = (uint32_t)world;
     fp.slot_begin = 0;
     fp.slot_end = sh.slots;
     fp.first = first;
@@ -1442,13 +1445,8 @@ int rt_unpack_accum(rt_context *ctx, const void *d_packed, size_t bytes, int src
     rt_shard_slots(ctx, world, &n);
     if (bytes != (size_t)n * sizeof(float4)) return fail(ctx, RT_EINVAL, "packed buffer must be %zu bytes", (size_t)n * sizeof(float4));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int keep_rank = ctx->rank, keep_world = ctx->world;
-    ctx->rank = src_rank;
-    ctx->world = world;
     float cam0[12] = {0};
-    FrameParams fp = frame_params(ctx, cam0, 0, 0, 0);
-    ctx->rank = keep_rank;
-    ctx->world = keep_world;
+    FrameParams fp = frame_params(ctx, cam0, 0, 0, 0, src_rank, world);  // the SENDER's shard
     if (fp.slot_end)
         hipLaunchKernelGGL(pt_unpack, dim3((fp.slot_end + 255) / 256), dim3(256), 0, ctx->stream, fp, (const float4 *)d_packed, ctx->d_accum);
     HIP_TRY(ctx, hipGetLastError());
