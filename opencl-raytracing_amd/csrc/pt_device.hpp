@@ -73,7 +73,9 @@ PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 #endif                     // (ds_read_b128 broadcast) instead of scalar loads; measured slower, DESIGN.md §5
 #define PT_LDS_SPHERE_CAP 256
 
-#define PT_LDS_MATERIALS 64  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
+#define PT_LDS_MATERIALS 64
+#define PT_LDS_WINNERS 64    // spheres whose (pos, r, mat) are also staged in LDS: the winner's record is
+                             // a per-lane fetch on the critical path of every bounce (global: ~600 cycles)  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
 #define PT_SPHERE_BATCH 4
 
 // Everything the kernels read.  Passed by value (kernarg segment → SGPRs); this
@@ -132,19 +134,32 @@ struct Ctx {
     const float4 *lmat;  // LDS: [2i] = (r,g,b,extra), [2i+1].x = type bits; nullptr → read global
     LaneCounters *cn;
     const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
+    const float4 *lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
 };
+#define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS)  // stage_materials' LDS footprint
 
 // ---- materials in LDS ----------------------------------------------------------
 // call at kernel start by every thread of the workgroup (contains a barrier)
 PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
-    if (sc.material_count > PT_LDS_MATERIALS) return nullptr;
-    for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
-        const rt_material &m = sc.materials[i];
-        lds[2 * i] = make_float4(m.color.x, m.color.y, m.color.z, m.extra_data);
-        lds[2 * i + 1] = make_float4(__int_as_float(m.type), 0.0f, 0.0f, 0.0f);
-    }
+    bool mats = sc.material_count <= PT_LDS_MATERIALS;
+    if (mats)
+        for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
+            const rt_material &m = sc.materials[i];
+            lds[2 * i] = make_float4(m.color.x, m.color.y, m.color.z, m.extra_data);
+            lds[2 * i + 1] = make_float4(__int_as_float(m.type), 0.0f, 0.0f, 0.0f);
+        }
+    // winner records of small sphere sets, after the materials: [2i] = (pos.xyz, r), [2i+1].x = mat_ID bits
+    if (sc.sphere_count <= PT_LDS_WINNERS)
+        for (uint32_t i = threadIdx.x; i < sc.sphere_count; i += blockDim.x) {
+            const rt_sphere &s = sc.spheres[i];
+            lds[2 * PT_LDS_MATERIALS + 2 * i] = make_float4(s.pos.x, s.pos.y, s.pos.z, s.r);
+            lds[2 * PT_LDS_MATERIALS + 2 * i + 1] = make_float4(__uint_as_float(s.mat_ID), 0.0f, 0.0f, 0.0f);
+        }
     __syncthreads();
-    return lds;
+    return mats ? lds : nullptr;
+}
+PT_DEV const float4 *staged_winners(const DeviceScene &sc, const float4 *lds) {
+    return sc.sphere_count <= PT_LDS_WINNERS ? lds + 2 * PT_LDS_MATERIALS : nullptr;
 }
 // PT_LDS_SPHERES experiment: stage the sphere test data of small scenes (after stage_materials' barrier
 // has been passed by every thread; contains its own barrier)
@@ -204,11 +219,16 @@ enum : uint32_t { K_SPHERE = 0u << 30, K_PLANE = 1u << 30, K_LENS = 2u << 30, K_
 
 // :149-174 with r² precomputed (same float product, computed once at upload).
 // Returns the accepted root, or a negative number.
+PT_DEV float sphere_root(float b, float cc, float dis);
 PT_DEV float sphere_t(const Ray &r, float4 s) {
     V3 oc = xyz(s) - r.o;
     float b = dot(oc, r.d);
     float cc = dot(oc, oc) - s.w;
     float dis = b * b - cc;
+    return sphere_root(b, cc, dis);
+}
+// second half of :149-174: the accepted root, or a negative number
+PT_DEV float sphere_root(float b, float cc, float dis) {
     float t = -1.0f;
     // Centre behind the origin (b < 0) and origin outside the sphere (cc > 0): the far root is
     // b + sqrt(b*b - cc) <= |b|·2^-23 < MIN_DISTANCE for |b| < 4096, the near root is negative —
@@ -326,6 +346,22 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     }
 }
 
+#ifndef PT_PACKED_SPHERES
+#define PT_PACKED_SPHERES 0  // A/B: two spheres per packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32)
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+// :149-174 for TWO spheres (cx, cy, cz, r²)×2 at once: every step up to the discriminant is one
+// packed-fp32 instruction — two IEEE binary32 results per lane, the same bits as two scalar ops.
+PT_DEV void sphere_pair_t(const Ray &r, float4 sa, float4 sb, float &tA, float &tB) {
+    f2 cx = {sa.x, sb.x}, cy = {sa.y, sb.y}, cz = {sa.z, sb.z}, r2 = {sa.w, sb.w};
+    f2 ocx = cx - r.o.x, ocy = cy - r.o.y, ocz = cz - r.o.z;
+    f2 b = (ocx * r.d.x + ocy * r.d.y) + ocz * r.d.z;
+    f2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
+    f2 dis = b * b - cc;
+    tA = sphere_root(b.x, cc.x, dis.x);
+    tB = sphere_root(b.y, cc.y, dis.y);
+}
+
 // :176-194
 PT_DEV float plane_t(const Ray &r, V3 p0, V3 n) {
     float a = dot(r.d, n);
@@ -420,11 +456,20 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             sp += PT_SPHERE_BATCH;  // the array ends with one dummy batch, so this prefetch is always in bounds
             float4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
             uint32_t i = b * PT_SPHERE_BATCH;
-            float t;
-            t = sphere_t(r, a0); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | i; }
-            t = sphere_t(r, a1); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 1); }
-            t = sphere_t(r, a2); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 2); }
-            t = sphere_t(r, a3); if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + 3); }
+            float t0, t1, t2, t3;
+            if (PT_PACKED_SPHERES) {
+                sphere_pair_t(r, a0, a1, t0, t1);
+                sphere_pair_t(r, a2, a3, t2, t3);
+            } else {
+                t0 = sphere_t(r, a0);
+                t1 = sphere_t(r, a1);
+                t2 = sphere_t(r, a2);
+                t3 = sphere_t(r, a3);
+            }
+            if (t0 > 0.0f && t0 < best_t) { best_t = t0; best_id = K_SPHERE | i; }
+            if (t1 > 0.0f && t1 < best_t) { best_t = t1; best_id = K_SPHERE | (i + 1); }
+            if (t2 > 0.0f && t2 < best_t) { best_t = t2; best_id = K_SPHERE | (i + 2); }
+            if (t3 > 0.0f && t3 < best_t) { best_t = t3; best_id = K_SPHERE | (i + 3); }
             a0 = n0; a1 = n1; a2 = n2; a3 = n3;
         }
     }
@@ -548,10 +593,17 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         V3 centre;
         float rad;
         if (kind == K_SPHERE) {
-            const rt_sphere &s = sc.spheres[idx];
-            centre = ld3(s.pos);
-            rad = s.r;
-            hit.mat = s.mat_ID;
+            if (c.lwin) {
+                float4 w = c.lwin[2 * idx];
+                centre = xyz(w);
+                rad = w.w;
+                hit.mat = __float_as_uint(c.lwin[2 * idx + 1].x);
+            } else {
+                const rt_sphere &s = sc.spheres[idx];
+                centre = ld3(s.pos);
+                rad = s.r;
+                hit.mat = s.mat_ID;
+            }
         } else {
             const rt_lens &l = sc.lenses[idx];
             int which = 0;

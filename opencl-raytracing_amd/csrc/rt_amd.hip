@@ -99,10 +99,11 @@ PT_DEV void accumulate(float4 *__restrict__ accum, size_t pix, V3 sum, uint32_t 
 template <int MODE, bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp, float4 *__restrict__ accum,
                                                  float4 *__restrict__ image, unsigned long long *counters) {
-    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+    c.lwin = staged_winners(sc, s_mat);
 
     uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t g = 1u << fp.group_log2;
@@ -148,10 +149,11 @@ template <bool COUNT, bool ACCEL>
 __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp, PixelRec *__restrict__ recs,
                                                  uint32_t *__restrict__ live, uint32_t *__restrict__ live_count,
                                                  float4 *__restrict__ accum, unsigned long long *counters) {
-    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+    c.lwin = staged_winners(sc, s_mat);
 #if PT_LDS_SPHERES
     __shared__ float4 s_sph[PT_LDS_SPHERE_CAP];
     c.lsph = stage_spheres(sc, s_sph);
@@ -196,10 +198,11 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
                                                   const uint32_t *__restrict__ live,
                                                   const uint32_t *__restrict__ live_count,
                                                   float4 *__restrict__ accum, unsigned long long *counters) {
-    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+    c.lwin = staged_winners(sc, s_mat);
 
     uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t g = 1u << fp.group_log2;
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
 #ifndef QUEUE_SLOTS
 #define QUEUE_SLOTS 512   // upper bound of samples a wave owns; the launch picks pixels_per_wave
 #endif
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 1   // idle lanes that trigger a refill
+#endif
 #ifndef QUEUE_TARGET
 #define QUEUE_TARGET 512  // samples per wave aimed for (A/B on MI355X: 256 and 512 tie at 64 spp, 512 wins at 256 spp)
 #endif
@@ -260,12 +266,13 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     LaneCounters cn;
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
+    c.lwin = staged_winners(sc, s_mat);
 #if PT_LDS_SPHERES
-    c.lsph = stage_spheres(sc, s_dyn + 2 * PT_LDS_MATERIALS);
+    c.lsph = stage_spheres(sc, s_dyn + PT_LDS_STATIC_FLOAT4);
 #endif
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    char *wave_lds = reinterpret_cast<char *>(s_dyn + 2 * PT_LDS_MATERIALS + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
+    char *wave_lds = reinterpret_cast<char *>(s_dyn + PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
         // ---- refill idle lanes from the queue
         bool need = !active;
         unsigned long long m = __ballot(need);
-        if (m && next < total) {
+        // refill when enough lanes idle (or none is active): the refill step issues for the whole wave
+        if (m && next < total && ((uint32_t)__popcll(m) >= PT_REFILL_MIN || m == ~0ull)) {
             uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (need && cand < total) {
                 idx = cand;
@@ -412,8 +420,9 @@ template <bool ACCEL>
 __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
                                                 const uint32_t *__restrict__ ys, const uint32_t *__restrict__ ss,
                                                 uint32_t n, float *__restrict__ out) {
-    __shared__ float4 s_mat[2 * PT_LDS_MATERIALS];
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
     Ctx c{sc, stage_materials(sc, s_mat), nullptr};
+    c.lwin = staged_winners(sc, s_mat);
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
@@ -909,7 +918,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         ppw = ppw < 1 ? 1 : (ppw > QUEUE_MAX_PIXELS ? QUEUE_MAX_PIXELS : ppw);
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
-        size_t lds_q = (2 * PT_LDS_MATERIALS + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) * sizeof(float4) +
+        size_t lds_q = (PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) * sizeof(float4) +
                        4 * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
