@@ -138,6 +138,13 @@ struct Ctx {
 };
 #define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS)  // stage_materials' LDS footprint
 
+// :402-403 — r0 = ((1 − ratio)/(1 + ratio))²
+PT_DEV float schlick_r0(float ratio) {
+    float r0 = (1.0f - ratio) / (1.0f + ratio);
+    r0 *= r0;
+    return r0;
+}
+
 // ---- materials in LDS ----------------------------------------------------------
 // call at kernel start by every thread of the workgroup (contains a barrier)
 PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
@@ -146,7 +153,11 @@ PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
         for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
             const rt_material &m = sc.materials[i];
             lds[2 * i] = make_float4(m.color.x, m.color.y, m.color.z, m.extra_data);
-            lds[2 * i + 1] = make_float4(__int_as_float(m.type), 0.0f, 0.0f, 0.0f);
+            // per-material constants of the glass interactions (:379,:402-403), computed once per
+            // workgroup by the same operations the bounce would perform: 1/extra and Schlick's r0²
+            // for both index ratios
+            float inv = 1.0f / m.extra_data;
+            lds[2 * i + 1] = make_float4(__int_as_float(m.type), inv, schlick_r0(m.extra_data), schlick_r0(inv));
         }
     // winner records of small sphere sets, after the materials: [2i] = (pos.xyz, r), [2i+1].x = mat_ID bits
     if (sc.sphere_count <= PT_LDS_WINNERS)
@@ -619,11 +630,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
 
 // ---- materials -------------------------------------------------------------------
 // :401-405
-PT_DEV float schlick(float cosine, float ratio) {
-    float r0 = (1.0f - ratio) / (1.0f + ratio);
-    r0 *= r0;
-    return r0 + (1.0f - r0) * pow5(1.0f - cosine);
-}
+PT_DEV float schlick(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosine); }
 
 // :105-107 with the bilinear definition of DESIGN.md (OpenCL 1.2 §8.2, edge clamp)
 PT_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -668,20 +675,32 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
         out = out * extra;  // :366 — only for t_reflective
     } else if (type == RT_REFRACTIVE || type == RT_DIELECTRIC) {
         V3 n;
-        float ratio;
+        float ratio, r0;
+        // 1/extra and Schlick's r0² per material: from the workgroup's LDS table when there is one
+        float inv_extra, r0_extra, r0_inv;
+        if (c.lmat) {
+            float4 x = c.lmat[2 * h.mat + 1];
+            inv_extra = x.y; r0_extra = x.z; r0_inv = x.w;
+        } else {
+            inv_extra = 1.0f / extra;
+            r0_extra = schlick_r0(extra);
+            r0_inv = schlick_r0(inv_extra);
+        }
         float cai = dot(r.d, h.n);  // cos of the incident angle
         if (cai > 0) {
             n = neg(h.n);
             ratio = extra;
+            r0 = r0_extra;
             cai = -cai;
         } else {
             n = h.n;
-            ratio = 1.0f / extra;
+            ratio = inv_extra;
+            r0 = r0_inv;
         }
         bool want = true;
         if (type == RT_DIELECTRIC) {
             if (COUNT) c.cn->c[CN_N_DIELECTRIC]++;
-            float prob = schlick(-cai, ratio);
+            float prob = schlick(-cai, r0);
             want = prob < rnd.u;
         }
         float disc = 1.0f - ratio * ratio * (1.0f - cai * cai);
@@ -749,7 +768,7 @@ PT_DEV Ray primary_ray(const float *cam, uint32_t x, uint32_t y, int w, int h) {
 struct PixelRec {        // 80 bytes
     float4 p_kind;       // hit point, w = bits: kind (0 final colour, 1 stochastic vertex) | depth << 8 | type << 16
     float4 n_extra;      // normal, material extra_data
-    float4 d;            // incoming ray direction
+    float4 d;            // incoming ray direction, w = material id bits
     float4 out;          // path colour so far (kind 1) or the pixel's radiance for every sample (kind 0)
     float4 col;          // material colour / texel
 };
@@ -783,7 +802,7 @@ PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
             uint32_t bits = REC_VERTEX | (i << 8) | ((uint32_t)type << 16);
             rec.p_kind = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(bits));
             rec.n_extra = make_float4(h.n.x, h.n.y, h.n.z, extra);
-            rec.d = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+            rec.d = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(h.mat));
             rec.out = make_float4(out.x, out.y, out.z, 0.0f);
             rec.col = make_float4(col.x, col.y, col.z, 0.0f);
             return rec;
@@ -813,7 +832,7 @@ PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, 
     h.n = xyz(rec.n_extra);
     h.u = h.v = 0.0f;
     h.tex = 0;
-    h.mat = 0;
+    h.mat = __float_as_uint(rec.d.w);
     V3 out = xyz(rec.out);
     Rnd rnd = fetch_rnd(c.sc.table, r.d, depth + sample, gx, gy);
     scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), rnd);

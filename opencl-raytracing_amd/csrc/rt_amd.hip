@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
                     extra = q1.w;
                     r.o = xyz(q0);
                     r.d = xyz(q2);
+                    h.mat = __float_as_uint(q2.w);
                     out = xyz(q3);
                     col = xyz(q4);
                     if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
