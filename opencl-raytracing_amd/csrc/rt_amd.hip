@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -637,6 +638,38 @@ struct BvhBuild {
     }
 };
 
+// per-face records (see DeviceScene::faces): the same binary32 operations hitTriangle performs.
+// base[m] = first record of mesh m; fr = 3 float4 per face + one dummy record.
+bool build_face_records(const rt_scene_desc *d, std::vector<uint32_t> &base, std::vector<float4> &fr) {
+    base.assign(d->mesh_count ? d->mesh_count : 1, 0u);
+    size_t total = 0;
+    for (uint32_t m = 0; m < d->mesh_count; m++) { base[m] = (uint32_t)total; total += d->meshes[m].face_count; }
+    if (total >= (1ull << 31)) return false;
+    fr.assign(3 * (total + 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (uint32_t m = 0; m < d->mesh_count; m++) {
+        const rt_mesh &me = d->meshes[m];
+        for (uint32_t f = 0; f < me.face_count; f++) {
+            const uint32_t *ib = d->indices + me.index_anchor + 3u * f;
+            const rt_float3 &A = d->vertices[me.vertex_anchor + ib[0]], &B = d->vertices[me.vertex_anchor + ib[1]],
+                            &C = d->vertices[me.vertex_anchor + ib[2]];
+            volatile float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
+            volatile float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
+            volatile float p1 = e1y * e2z, p2 = e1z * e2y, p3 = e1z * e2x, p4 = e1x * e2z, p5 = e1x * e2y, p6 = e1y * e2x;
+            volatile float cx = p1 - p2, cy = p3 - p4, cz = p5 - p6;          // cross(e1, e2)
+            volatile float xx = cx * cx, yy = cy * cy, zz = cz * cz;
+            volatile float s2 = xx + yy;
+            volatile float s3 = s2 + zz;                                        // dot = (x*x + y*y) + z*z
+            volatile float len = std::sqrt((float)s3);
+            volatile float nx = cx / len, ny = cy / len, nz = cz / len;          // normalize
+            float4 *q = &fr[3 * ((size_t)base[m] + f)];
+            q[0] = make_float4(A.x, A.y, A.z, e1x);
+            q[1] = make_float4(e1y, e1z, e2x, e2y);
+            q[2] = make_float4(e2z, nx, ny, nz);
+        }
+    }
+    return true;
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -1121,33 +1154,9 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         ctx->sphere_batches = batches;
     }
     {
-        // per-face records (see DeviceScene::faces): the same binary32 operations hitTriangle performs
-        std::vector<uint32_t> base(d->mesh_count ? d->mesh_count : 1, 0u);
-        size_t total = 0;
-        for (uint32_t m = 0; m < d->mesh_count; m++) { base[m] = (uint32_t)total; total += d->meshes[m].face_count; }
-        if (total >= (1ull << 31)) return fail(ctx, RT_EINVAL, "too many faces");
-        std::vector<float4> fr(3 * (total + 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        for (uint32_t m = 0; m < d->mesh_count; m++) {
-            const rt_mesh &me = d->meshes[m];
-            for (uint32_t f = 0; f < me.face_count; f++) {
-                const uint32_t *ib = d->indices + me.index_anchor + 3u * f;
-                const rt_float3 &A = d->vertices[me.vertex_anchor + ib[0]], &B = d->vertices[me.vertex_anchor + ib[1]],
-                                &C = d->vertices[me.vertex_anchor + ib[2]];
-                volatile float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
-                volatile float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
-                volatile float p1 = e1y * e2z, p2 = e1z * e2y, p3 = e1z * e2x, p4 = e1x * e2z, p5 = e1x * e2y, p6 = e1y * e2x;
-                volatile float cx = p1 - p2, cy = p3 - p4, cz = p5 - p6;          // cross(e1, e2)
-                volatile float xx = cx * cx, yy = cy * cy, zz = cz * cz;
-                volatile float s2 = xx + yy;
-                volatile float s3 = s2 + zz;                                        // dot = (x*x + y*y) + z*z
-                volatile float len = std::sqrt((float)s3);
-                volatile float nx = cx / len, ny = cy / len, nz = cz / len;          // normalize
-                float4 *q = &fr[3 * ((size_t)base[m] + f)];
-                q[0] = make_float4(A.x, A.y, A.z, e1x);
-                q[1] = make_float4(e1y, e1z, e2x, e2y);
-                q[2] = make_float4(e2z, nx, ny, nz);
-            }
-        }
+        std::vector<uint32_t> base;
+        std::vector<float4> fr;
+        if (!build_face_records(d, base, fr)) return fail(ctx, RT_EINVAL, "too many faces");
         HIP_TRY(ctx, ctx->faces.upload(fr.data(), fr.size()));
         HIP_TRY(ctx, ctx->mesh_face_base.upload(base.data(), d->mesh_count));
         // per-mesh BVHs for the "first front-facing hit in face order" rule (pt_mesh_bvh.hpp)
@@ -1424,6 +1433,203 @@ int rt_device_accum(rt_context *ctx, void **d_rgba) {
 int rt_enable_counters(rt_context *ctx, int enable) {
     if (!ctx) return RT_EINVAL;
     ctx->count_enabled = enable != 0;
+    return RT_OK;
+}
+
+// ---- host-only self-check of the acceleration structures ------------------------------------
+extern "C++" {
+namespace {
+struct BvhWalkStats { uint64_t nodes = 0, leaves = 0, prims = 0, max_depth = 0; };
+
+// walk a tree the way the kernels do (three-state stackless walk, every box "hit", a fixed
+// direction octant) and check the links; stride = float4 per node; returns "" or an error
+std::string host_walk(const std::vector<float4> &nodes, uint32_t stride, uint32_t root, uint32_t far_first,
+                      std::vector<uint32_t> &leaf_visits, BvhWalkStats &st) {
+    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
+    uint32_t n_nodes = (uint32_t)(nodes.size() / stride), cur = root;
+    int state = FROM_PARENT;
+    for (uint64_t guard = 0;; guard++) {
+        if (guard > 3ull * n_nodes + 8) return "walk does not terminate";
+        if (cur >= n_nodes) return "node index out of range";
+        uint32_t A, B;
+        memcpy(&A, &nodes[(size_t)stride * cur].w, 4);
+        memcpy(&B, &nodes[(size_t)stride * cur + 1].w, 4);
+        uint32_t parent = A & 0x0FFFFFFFu, sibling = (cur & 1u) ? cur + 1u : cur - 1u;
+        if (state == FROM_CHILD) {
+            if (cur == root) return "";
+            uint32_t pA, pB;
+            memcpy(&pA, &nodes[(size_t)stride * parent].w, 4);
+            memcpy(&pB, &nodes[(size_t)stride * parent + 1].w, 4);
+            uint32_t pnear = pB + ((far_first >> ((pA >> 28) & 3u)) & 1u);
+            if (cur == pnear) { cur = sibling; state = FROM_SIBLING; } else cur = parent;
+            continue;
+        }
+        st.nodes++;
+        bool leaf = (B & 0x80000000u) != 0;
+        if (leaf) {
+            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+            st.leaves++;
+            for (uint32_t k = 0; k < cnt; k++) {
+                if (first + k >= leaf_visits.size()) return "leaf slot out of range";
+                leaf_visits[first + k]++;
+            }
+        }
+        if (!leaf) {
+            if (((A >> 28) & 3u) > 2) return "bad split axis";
+            if (!(B & 1u)) return "left child at an even index";
+            cur = B + ((far_first >> ((A >> 28) & 3u)) & 1u);
+            state = FROM_PARENT;
+        } else if (cur == root) return "";
+        else if (state == FROM_PARENT) { cur = sibling; state = FROM_SIBLING; }
+        else { cur = parent; state = FROM_CHILD; }
+    }
+}
+
+// recursive structural check: child boxes inside the parent's, parent links, depth
+std::string host_check_tree(const std::vector<float4> &nodes, uint32_t stride, uint32_t me, uint32_t parent, bool is_root,
+                            uint32_t depth, BvhWalkStats &st) {
+    const float4 &lo = nodes[(size_t)stride * me], &hi = nodes[(size_t)stride * me + 1];
+    uint32_t A, B;
+    memcpy(&A, &lo.w, 4);
+    memcpy(&B, &hi.w, 4);
+    if ((A & 0x0FFFFFFFu) != parent) return "wrong parent link";
+    st.max_depth = std::max<uint64_t>(st.max_depth, depth);
+    if (!is_root) {
+        const float4 &plo = nodes[(size_t)stride * parent], &phi = nodes[(size_t)stride * parent + 1];
+        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
+            return "child box not inside its parent's";
+    }
+    if (B & 0x80000000u) return "";
+    for (uint32_t k = 0; k < 2; k++) {
+        std::string e = host_check_tree(nodes, stride, B + k, me, false, depth + 1, st);
+        if (!e.empty()) return e;
+    }
+    return "";
+}
+}  // namespace
+}  // extern "C++"
+
+int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, size_t err_len) {
+    auto bad = [&](const std::string &m) {
+        if (err && err_len) snprintf(err, err_len, "%s", m.c_str());
+        return RT_EINVAL;
+    };
+    if (!d || !stats) return RT_EINVAL;
+    memset(stats, 0, 8 * sizeof(uint64_t));
+    // ---- sphere BVH
+    if (d->sphere_count) {
+        BvhBuild bb;
+        bb.sph = d->spheres;
+        bb.order.resize(d->sphere_count);
+        for (uint32_t i = 0; i < d->sphere_count; i++) bb.order[i] = i;
+        bb.build(0, d->sphere_count);
+        BvhWalkStats st;
+        std::string e = host_check_tree(bb.nodes, 2, 0, 0, true, 0, st);
+        if (!e.empty()) return bad("sphere bvh: " + e);
+        for (uint32_t oct = 0; oct < 8; oct++) {
+            std::vector<uint32_t> visits(bb.leaf_idx.size(), 0);
+            BvhWalkStats w;
+            e = host_walk(bb.nodes, 2, 0, oct, visits, w);
+            if (!e.empty()) return bad("sphere bvh: " + e);
+            for (uint32_t v : visits) if (v != 1) return bad("sphere bvh: a leaf slot is not visited exactly once");
+            st.nodes = w.nodes; st.leaves = w.leaves;
+        }
+        std::vector<uint32_t> seen(d->sphere_count, 0);
+        if (bb.leaf_idx.size() != d->sphere_count) return bad("sphere bvh: leaf slot count != sphere count");
+        for (uint32_t i : bb.leaf_idx) { if (i >= d->sphere_count || seen[i]++) return bad("sphere bvh: sphere missing or duplicated"); }
+        // every sphere inside its leaf's box
+        for (uint32_t n = 0; n < bb.nodes.size() / 2; n++) {
+            uint32_t B;
+            memcpy(&B, &bb.nodes[2 * n + 1].w, 4);
+            if (!(B & 0x80000000u)) continue;
+            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const rt_sphere &sp = d->spheres[bb.leaf_idx[first + k]];
+                const float4 &lo = bb.nodes[2 * n], &hi = bb.nodes[2 * n + 1];
+                float r = std::fabs(sp.r);
+                if (sp.pos.x - r < lo.x || sp.pos.y - r < lo.y || sp.pos.z - r < lo.z || sp.pos.x + r > hi.x ||
+                    sp.pos.y + r > hi.y || sp.pos.z + r > hi.z)
+                    return bad("sphere bvh: sphere outside its leaf box");
+            }
+        }
+        stats[0] = st.nodes; stats[1] = st.leaves; stats[2] = st.max_depth;
+    }
+    // ---- mesh BVHs
+    std::vector<uint32_t> base;
+    std::vector<float4> fr;
+    if (!build_face_records(d, base, fr)) return bad("too many faces");
+    for (uint32_t m = 0; m < d->mesh_count; m++) {
+        uint32_t nf = d->meshes[m].face_count;
+        if (nf < MESH_BVH_MIN_FACES) continue;
+        std::vector<float4> nodes, lfaces;
+        std::vector<uint32_t> lidx;
+        MeshBvhBuilder mb;
+        mb.rec = &fr[3 * (size_t)base[m]];
+        mb.n_faces = nf;
+        mb.nodes = &nodes;
+        mb.leaf_faces = &lfaces;
+        mb.leaf_idx = &lidx;
+        uint32_t root = mb.build();
+        BvhWalkStats st;
+        std::string e = host_check_tree(nodes, 4, root, root, true, 0, st);
+        if (!e.empty()) return bad("mesh bvh: " + e);
+        for (uint32_t oct = 0; oct < 8; oct++) {
+            std::vector<uint32_t> visits(lidx.size(), 0);
+            BvhWalkStats w;
+            e = host_walk(nodes, 4, root, oct, visits, w);
+            if (!e.empty()) return bad("mesh bvh: " + e);
+            for (uint32_t v : visits) if (v != 1) return bad("mesh bvh: a leaf slot is not visited exactly once");
+            st.nodes = w.nodes; st.leaves = w.leaves;
+        }
+        if (lidx.size() != nf) return bad("mesh bvh: leaf slot count != face count");
+        std::vector<uint32_t> seen(nf, 0);
+        for (uint32_t i : lidx) { if (i >= nf || seen[i]++) return bad("mesh bvh: face missing or duplicated"); }
+        // per node: min face, normal cone, edge and quality bounds, faces inside leaf boxes — from the leaves up
+        std::function<std::string(uint32_t, std::vector<uint32_t> &)> collect = [&](uint32_t n, std::vector<uint32_t> &faces) -> std::string {
+            uint32_t B;
+            memcpy(&B, &nodes[4 * (size_t)n + 1].w, 4);
+            if (B & 0x80000000u) {
+                uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+                for (uint32_t k = 0; k < cnt; k++) faces.push_back(lidx[first + k]);
+            } else {
+                for (uint32_t k = 0; k < 2; k++) {
+                    std::vector<uint32_t> sub;
+                    std::string er = collect(B + k, sub);
+                    if (!er.empty()) return er;
+                    faces.insert(faces.end(), sub.begin(), sub.end());
+                }
+            }
+            const float4 &lo = nodes[4 * (size_t)n], &hi = nodes[4 * (size_t)n + 1], &cone = nodes[4 * (size_t)n + 2], &ex = nodes[4 * (size_t)n + 3];
+            uint32_t min_face;
+            memcpy(&min_face, &ex.y, 4);
+            uint32_t true_min = 0xFFFFFFFFu;
+            for (uint32_t f : faces) {
+                true_min = std::min(true_min, f);
+                const float4 *q = mb.rec + 3 * (size_t)f;
+                double A[3] = {q[0].x, q[0].y, q[0].z}, e1[3] = {q[0].w, q[1].x, q[1].y}, e2[3] = {q[1].z, q[1].w, q[2].x};
+                for (int k = 0; k < 3; k++) {
+                    const float l = (&lo.x)[k], h = (&hi.x)[k];
+                    double p[3] = {A[k], A[k] + e1[k], A[k] + e2[k]};
+                    for (double v : p) if (v < l || v > h) return std::string("face outside its node box");
+                }
+                double nl = std::sqrt((double)q[2].y * q[2].y + (double)q[2].z * q[2].z + (double)q[2].w * q[2].w);
+                if (std::isfinite(nl) && nl > 0.5 && ex.w > 0.0f) {
+                    double dt = (cone.x * q[2].y + cone.y * q[2].z + cone.z * q[2].w) / nl;
+                    double cos_a = cone.w, sin_a = ex.x;
+                    // the face normal must lie inside the cone (cos/sin describe the half angle; 0/1 = hemisphere or wider)
+                    if (!(cos_a == 0.0 && sin_a == 1.0) && dt < cos_a - 1e-5) return std::string("face normal outside the node's cone");
+                }
+                double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                if (l1 > ex.z * 1.0001 || l2 > ex.z * 1.0001) return std::string("edge longer than the node's bound");
+            }
+            if (true_min != min_face) return std::string("wrong smallest face index");
+            return "";
+        };
+        std::vector<uint32_t> all;
+        e = collect(root, all);
+        if (!e.empty()) return bad("mesh bvh: " + e);
+        stats[3] += st.nodes; stats[4] += st.leaves; stats[5] = std::max(stats[5], st.max_depth); stats[6]++;
+    }
     return RT_OK;
 }
 

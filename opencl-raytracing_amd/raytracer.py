@@ -27,7 +27,7 @@ SYMBOLS = (
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
     "rt_kernel_ms_history", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
-    "rt_get_debug_counters",
+    "rt_get_debug_counters", "rt_debug_check_accel",
 )
 
 
@@ -102,6 +102,20 @@ def load_library(path=LIB_PATH):
         raise OSError("librt_amd.so ABI %d != expected %d" % (lib.rt_abi_version(), _abi.RT_ABI_VERSION))
     _lib = lib
     return lib
+
+
+def check_accel(scene):
+    """Host-only self-check of the BVHs rt_set_scene would build for `scene` (no device needed).
+    → stats dict; raises RtError with the violated invariant."""
+    lib = load_library()
+    d = scene.desc()
+    stats = (C.c_uint64 * 8)()
+    err = C.create_string_buffer(256)
+    rc = lib.rt_debug_check_accel(C.byref(d), stats, err, 256)
+    if rc:
+        raise RtError(rc, err.value.decode() or "accel check failed")
+    keys = ("sphere_nodes", "sphere_leaves", "sphere_depth", "mesh_nodes", "mesh_leaves", "mesh_depth", "meshes")
+    return dict(zip(keys, [int(v) for v in stats]))
 
 
 def make_random_table(seed):
