@@ -134,13 +134,14 @@ def main():
     if world != args.gpus:
         sys.exit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" %
                  (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local)
+    device = local % torch.cuda.device_count()   # == local on a full node; rehearsals may oversubscribe a GPU
+    torch.cuda.set_device(device)
     import torch.distributed as dist
 
     wl = rt.workloads.get(args.workload)
     base_spp = args.spp or wl.spp
     spp = base_spp * world                       # weak scaling: per-GPU pixel-samples fixed
-    tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=local, seed=rt.workloads.SEED)
+    tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
     renderer = dist_mod.ShardedRenderer(dist_mod.GpuShard(tracer, rank, world), rank, world, exchange=args.exchange)
     table = tracer.getRandomTable() if rank == 0 else None
 

@@ -65,7 +65,9 @@ def init_process_group(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RT_DIST_BACKEND=gloo rehearses the multi-rank path on fewer GPUs than ranks (gloo moves CUDA
+            # tensors through the host for reduce/all_reduce; RCCL refuses two ranks on one device)
+            backend = os.environ.get("RT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -148,10 +150,19 @@ class ShardedRenderer:
                     reduce_frame(sh.accum, dst=0)
                 else:
                     sh.pack(self.send)
-                    dist.gather(self.send, self.recv, dst=0)
-                    if self.rank == 0:
-                        for r in range(1, self.world):   # rank 0's own tiles are already in place
-                            sh.unpack(self.recv[r], r)
+                    try:
+                        dist.gather(self.send, self.recv, dst=0)
+                    except (RuntimeError, ValueError, NotImplementedError) as e:
+                        # a backend without gather for these tensors raises on every rank alike:
+                        # all ranks fall back to the full-frame reduce, this frame included
+                        import warnings
+                        warnings.warn("gather exchange unavailable (%s); using the full-frame reduce" % e)
+                        self.exchange = "reduce"
+                        reduce_frame(sh.accum, dst=0)
+                    else:
+                        if self.rank == 0:
+                            for r in range(1, self.world):   # rank 0's own tiles are already in place
+                                sh.unpack(self.recv[r], r)
             if self.rank == 0:
                 sh.resolve()
 
