@@ -12,7 +12,10 @@
 //     samples), so primitive indices are wave-uniform: primitive records are
 //     fetched with SCALAR loads (s_load → scalar cache → L2), four spheres per
 //     batch with the next batch prefetched, and cost no VGPRs and no LDS traffic;
-//   * materials (per-lane index) are staged in LDS once per workgroup;
+//   * materials (per-lane index), their glass constants and the winner records of small sphere
+//     sets are staged in LDS once per workgroup;
+//   * large sphere sets and large meshes go through conservative BVHs that return the
+//     brute-force answer bit for bit (hit_spheres_bvh, pt_mesh_bvh.hpp);
 //   * the nearest-hit search keeps only (t, id) per lane and rebuilds the hit
 //     record of the winner afterwards (same arithmetic → same bits);
 //   * every material kind ends in ONE shared "new direction" tail, so lanes on
