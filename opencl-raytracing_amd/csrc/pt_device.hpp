@@ -76,6 +76,23 @@ PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 #endif                     // (ds_read_b128 broadcast) instead of scalar loads; measured slower, DESIGN.md §5
 #define PT_LDS_SPHERE_CAP 256
 
+#ifndef PT_NO_MODELS
+#define PT_NO_MODELS 0  // experiment: compile the mesh code out
+#endif
+#ifndef PT_STAMPS
+#define PT_STAMPS 0   // diagnostic build: s_memtime shares of the queue kernel's sections (never timed)
+#endif
+#if PT_STAMPS
+#define PT_STAMP(c, k)                                                         \
+    do {                                                                       \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+        (c).st[k] += now_ - (c).st_last;                                       \
+        (c).st_last = now_;                                                    \
+    } while (0)
+#else
+#define PT_STAMP(c, k) do { } while (0)
+#endif
+
 #define PT_LDS_MATERIALS 64
 #define PT_LDS_WINNERS 64    // spheres whose (pos, r, mat) are also staged in LDS: the winner's record is
                              // a per-lane fetch on the critical path of every bounce (global: ~600 cycles)  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
@@ -138,6 +155,10 @@ struct Ctx {
     LaneCounters *cn;
     const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
     const float4 *lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
+#if PT_STAMPS
+    mutable unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    mutable unsigned long long st_last = 0;
+#endif
 };
 #define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS)  // stage_materials' LDS footprint
 
@@ -241,22 +262,36 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float dis = b * b - cc;
     return sphere_root(b, cc, dis);
 }
-// second half of :149-174: the accepted root, or a negative number
-PT_DEV float sphere_root(float b, float cc, float dis) {
+#ifndef PT_BATCH_ROOTS
+#define PT_BATCH_ROOTS 0  // A/B: 1 = the square-root path of a sphere batch runs once per ROUND (lanes pick their
+#endif                    // first candidate) instead of once per sphere with a handful of lanes active; no gain measured
+// Does this sphere need its roots?  Centre behind the origin (b < 0) and origin outside the sphere
+// (cc > 0): the far root is b + sqrt(b*b - cc) <= |b|·2^-23 < MIN_DISTANCE for |b| < 4096, the near
+// root is negative — the reference rejects both, so the square root is skipped.  Exact.
+PT_DEV bool sphere_needs_roots(float b, float cc, float dis) {
+    return dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > -4096.0f);
+}
+// :155-171 — the accepted root for dis > 0, or a negative number
+PT_DEV float sphere_roots(float b, float dis) {
+    float d = sqrtf(dis);
     float t = -1.0f;
-    // Centre behind the origin (b < 0) and origin outside the sphere (cc > 0): the far root is
-    // b + sqrt(b*b - cc) <= |b|·2^-23 < MIN_DISTANCE for |b| < 4096, the near root is negative —
-    // the reference rejects both, so the square root is skipped.  Exact, not an approximation.
-    if (dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > -4096.0f)) {
-        float d = sqrtf(dis);
-        float t0 = b - d;
-        if (in_range(t0)) t = t0;
-        else {
-            float t1 = b + d;
-            if (in_range(t1)) t = t1;
-        }
+    float t0 = b - d;
+    if (in_range(t0)) t = t0;
+    else {
+        float t1 = b + d;
+        if (in_range(t1)) t = t1;
     }
     return t;  // accepted roots are >= MIN_DISTANCE > 0
+}
+// second half of :149-174: the accepted root, or a negative number
+PT_DEV float sphere_root(float b, float cc, float dis) {
+    return sphere_needs_roots(b, cc, dis) ? sphere_roots(b, dis) : -1.0f;
+}
+PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis) {
+    V3 oc = xyz(s) - r.o;
+    b = dot(oc, r.d);
+    cc = dot(oc, oc) - s.w;
+    dis = b * b - cc;
 }
 
 // ---- sphere BVH -------------------------------------------------------------------
@@ -468,8 +503,33 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
         for (uint32_t b = 0; b < sc.sphere_batches; b++) {
             sp += PT_SPHERE_BATCH;  // the array ends with one dummy batch, so this prefetch is always in bounds
-            float4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
+            float4 n0_ = sp[0], n1_ = sp[1], n2_ = sp[2], n3_ = sp[3];
             uint32_t i = b * PT_SPHERE_BATCH;
+            if (PT_BATCH_ROOTS) {
+                // discriminants of the four spheres for every lane, then the (long, rarely needed)
+                // root computation in rounds: each lane takes its first pending sphere, so the
+                // sqrt path runs with many lanes active instead of once per sphere with a few.
+                // Per lane the spheres are still visited in index order (strict '<' keeps ties).
+                float b0, c0, d0, b1, c1, d1, b2, c2, d2, b3, c3, d3;
+                sphere_disc(r, a0, b0, c0, d0);
+                sphere_disc(r, a1, b1, c1, d1);
+                sphere_disc(r, a2, b2, c2, d2);
+                sphere_disc(r, a3, b3, c3, d3);
+                bool n0 = sphere_needs_roots(b0, c0, d0), n1 = sphere_needs_roots(b1, c1, d1);
+                bool n2 = sphere_needs_roots(b2, c2, d2), n3 = sphere_needs_roots(b3, c3, d3);
+                while (__any(n0 || n1 || n2 || n3)) {
+                    if (n0 || n1 || n2 || n3) {
+                        uint32_t j = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
+                        float bb = n0 ? b0 : (n1 ? b1 : (n2 ? b2 : b3));
+                        float dd = n0 ? d0 : (n1 ? d1 : (n2 ? d2 : d3));
+                        float t = sphere_roots(bb, dd);
+                        if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + j); }
+                        n0 = n0 && j != 0u; n1 = n1 && j != 1u; n2 = n2 && j != 2u; n3 = n3 && j != 3u;
+                    }
+                }
+                a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
+                continue;
+            }
             float t0, t1, t2, t3;
             if (PT_PACKED_SPHERES) {
                 sphere_pair_t(r, a0, a1, t0, t1);
@@ -484,9 +544,10 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             if (t1 > 0.0f && t1 < best_t) { best_t = t1; best_id = K_SPHERE | (i + 1); }
             if (t2 > 0.0f && t2 < best_t) { best_t = t2; best_id = K_SPHERE | (i + 2); }
             if (t3 > 0.0f && t3 < best_t) { best_t = t3; best_id = K_SPHERE | (i + 3); }
-            a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
         }
     }
+    PT_STAMP(c, 2);
     for (uint32_t i = 0; i < sc.plane_count; i++) {
         const rt_plane &p = sc.planes[i];
         float t = plane_t(r, ld3(p.pos), ld3(p.normal));
@@ -503,7 +564,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             best_id = K_LENS | i;
         }
     }
-    for (uint32_t mo = 0; mo < sc.model_count; mo++) {
+    for (uint32_t mo = 0; mo < (PT_NO_MODELS ? 0u : sc.model_count); mo++) {
         const rt_model &model = sc.models[mo];
         float model_best = RT_MAX_DISTANCE;  // hitModel's own hit_min (:307)
         uint32_t m_id = PT_NO_HIT, m_face = 0;
@@ -578,6 +639,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         c.cn->c[CN_T_LENS] += sc.lens_count;
         c.cn->c[CN_T_MODEL] += sc.model_count;
     }
+    PT_STAMP(c, 3);
     if (best_id == PT_NO_HIT) return false;
 
     // rebuild the winner's record with the reference's arithmetic

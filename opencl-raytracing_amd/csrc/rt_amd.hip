@@ -315,7 +315,11 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     rnd.v = mk(0.0f, 0.0f, 0.0f);
     rnd.u = 0.0f;
 
+#if PT_STAMPS
+    c.st_last = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
+        PT_STAMP(c, 5);
         // ---- refill idle lanes from the queue
         bool need = !active;
         unsigned long long m = __ballot(need);
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
             if (next >= total) break;
             continue;  // every candidate was a final-colour pixel: keep draining the queue
         }
+        PT_STAMP(c, 0);
         // ---- one material interaction for every active lane
         if (active) {
             if (!PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
                 active = false;
             }
         }
+        PT_STAMP(c, 1);
         // ---- nearest hit for every lane still active; the table reads of the NEXT material
         // interaction are issued first (they depend on the ray direction only)
         if (active) {
@@ -397,7 +403,12 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
                 active = false;
             }
         }
+        PT_STAMP(c, 4);
     }
+#if PT_STAMPS
+    if (lane == 0 && npix)
+        for (int k = 0; k < 6; k++) atomicAdd(&counters[(size_t)COUNTER_REPLICAS * COUNTER_STRIDE + k], c.st[k]);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -1034,8 +1045,8 @@ int rt_create(int device, int width, int height, rt_context **out) {
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < rt_context::EV_RING; i++)
         if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
-    if (hipMalloc((void **)&ctx->d_counters, COUNTER_REPLICAS * COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, COUNTER_REPLICAS * COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
+    if (hipMalloc((void **)&ctx->d_counters, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
     if ((rc = rt_set_seed(ctx, 0xC0FFEEull)) != RT_OK) return bail(rc);
     if ((rc = rt_set_textures(ctx, nullptr, 0, 0, 0)) != RT_OK) return bail(rc);
@@ -1718,6 +1729,17 @@ int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]) {
         out[0] += h[(size_t)r * COUNTER_STRIDE + 14];
         out[1] += h[(size_t)r * COUNTER_STRIDE + 15];
     }
+#if PT_STAMPS
+    {   // diagnostic build: print the s_memtime shares of pt_samples_q's sections
+        unsigned long long st[8];
+        if (hipMemcpy(st, ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+            const char *names[6] = {"refill", "scatter", "hit:spheres", "hit:planes/lenses/models", "hit:rebuild+material", "loop"};
+            double tot = 0;
+            for (int k = 0; k < 6; k++) tot += (double)st[k];
+            for (int k = 0; k < 6; k++) fprintf(stderr, "[stamps] %-26s %5.1f %%\n", names[k], tot > 0 ? 100.0 * st[k] / tot : 0.0);
+        }
+    }
+#endif
     return RT_OK;
 }
 
