@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    const float inv_count = 1.0f / (float)count;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     uint32_t idx = 0, depth = 0, sample = 0, gx = 0, gy = 0;
@@ -328,8 +329,10 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
             uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (need && cand < total) {
                 idx = cand;
-                uint32_t p = 0;
-                for (uint32_t k = 1; k < npix; k++) p += (idx >= k * count) ? 1u : 0u;
+                // pixel of this queue entry: p = idx / count, exactly, without an integer divide:
+                // (idx + 0.5)/count lies >= 0.5/count away from every integer, far more than the rounding
+                // of the float product (idx < 8192, count <= 512)
+                uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);
                 sample = fp.first + (idx - p * count);
                 float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
                        q4 = rec[5 * p + 4];
