@@ -155,12 +155,14 @@ struct Ctx {
     LaneCounters *cn;
     const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
     const float4 *lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
+    const float4 *lpln = nullptr;  // LDS (normal, mat) of small plane sets, or nullptr
 #if PT_STAMPS
     mutable unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     mutable unsigned long long st_last = 0;
 #endif
 };
-#define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS)  // stage_materials' LDS footprint
+#define PT_LDS_PLANES 16     // planes whose (normal, mat) are staged likewise
+#define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS + PT_LDS_PLANES)  // stage_materials' LDS footprint
 
 // :402-403 — r0 = ((1 − ratio)/(1 + ratio))²
 PT_DEV float schlick_r0(float ratio) {
@@ -190,11 +192,21 @@ PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
             lds[2 * PT_LDS_MATERIALS + 2 * i] = make_float4(s.pos.x, s.pos.y, s.pos.z, s.r);
             lds[2 * PT_LDS_MATERIALS + 2 * i + 1] = make_float4(__uint_as_float(s.mat_ID), 0.0f, 0.0f, 0.0f);
         }
+    // plane winner records: (normal.xyz, mat_ID bits)
+    if (sc.plane_count <= PT_LDS_PLANES)
+        for (uint32_t i = threadIdx.x; i < sc.plane_count; i += blockDim.x) {
+            const rt_plane &p = sc.planes[i];
+            lds[2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS + i] =
+                make_float4(p.normal.x, p.normal.y, p.normal.z, __uint_as_float(p.mat_ID));
+        }
     __syncthreads();
     return mats ? lds : nullptr;
 }
 PT_DEV const float4 *staged_winners(const DeviceScene &sc, const float4 *lds) {
     return sc.sphere_count <= PT_LDS_WINNERS ? lds + 2 * PT_LDS_MATERIALS : nullptr;
+}
+PT_DEV const float4 *staged_planes(const DeviceScene &sc, const float4 *lds) {
+    return sc.plane_count <= PT_LDS_PLANES ? lds + 2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS : nullptr;
 }
 // PT_LDS_SPHERES experiment: stage the sphere test data of small scenes (after stage_materials' barrier
 // has been passed by every thread; contains its own barrier)
@@ -648,10 +660,17 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
     hit.u = hit.v = 0.0f;
     hit.tex = 0;
     if (kind == K_PLANE) {
-        const rt_plane &p = sc.planes[idx];
-        V3 n = ld3(p.normal);
+        V3 n;
+        if (c.lpln) {
+            float4 w = c.lpln[idx];
+            n = xyz(w);
+            hit.mat = __float_as_uint(w.w);
+        } else {
+            const rt_plane &p = sc.planes[idx];
+            n = ld3(p.normal);
+            hit.mat = p.mat_ID;
+        }
         hit.n = neg(n) * sign1(dot(r.d, n));  // :187
-        hit.mat = p.mat_ID;
     } else if (kind == K_MESH) {
         const rt_mesh &mesh = sc.meshes[idx];
         const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * best_face;

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void pt_render(DeviceScene sc, FrameParams fp,
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
     c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
 
     uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t g = 1u << fp.group_log2;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
     c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
 #if PT_LDS_SPHERES
     __shared__ float4 s_sph[PT_LDS_SPHERE_CAP];
     c.lsph = stage_spheres(sc, s_sph);
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
     c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
 
     uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t g = 1u << fp.group_log2;
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     if (COUNT) zero_counters(cn);
     Ctx c{sc, stage_materials(sc, s_mat), &cn};
     c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
 #if PT_LDS_SPHERES
     c.lsph = stage_spheres(sc, s_dyn + PT_LDS_STATIC_FLOAT4);
 #endif
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, 
     __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
     Ctx c{sc, stage_materials(sc, s_mat), nullptr};
     c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
