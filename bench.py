@@ -193,6 +193,7 @@ def main():
         ms_per_step = wall_max / args.steps * 1e3
         value = total_samples * args.steps / wall_max / 1e6
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        flops = 17 * cn.t_sphere + 11 * cn.t_plane + 60 * cn.t_lens + 35 * cn.t_tri + 60 * cn.h_bounce
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
@@ -214,7 +215,13 @@ def main():
                          "kernel": "pt_prefix + pt_samples_q (one fused trace call)", "kernel_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_pixel_sample": round(alg_bytes / max(my_samples, 1), 1),
-                         "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3)},
+                         "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
+                         # SURVEY §8d's side figure: useful fp32 work of the REFERENCE's loops at its per-test
+                         # flop counts (sphere 17, plane 11, lens 60, triangle 35, shading 60 per hit) against the
+                         # vector peak without FMA (the parity contract forbids contraction): 157.3 / 2 TFLOP/s
+                         "valu": {"flop_per_launch_est": int(flops), "achieved": round(flops / (launch_ms * 1e-3) / 1e12, 2),
+                                  "peak": 78.6, "unit": "TFLOP/s (fp32 vector, no FMA)",
+                                  "frac": round(flops / (launch_ms * 1e-3) / 1e12 / 78.6, 4)}},
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
         }
         if world == 1 and not args.no_parity_check:

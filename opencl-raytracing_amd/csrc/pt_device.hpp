@@ -65,7 +65,7 @@ PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 
 // tuning switches (A/B-tested on MI355X; results never depend on them)
 #ifndef PT_RNG_PREFETCH
-#define PT_RNG_PREFETCH 0  // issue the table gathers before the nearest-hit search
+#define PT_RNG_PREFETCH 0  // 1: issue the table gathers before the nearest-hit search; 2: right after it, for lanes that go on
 #endif
 #ifndef PT_BEHIND_SKIP
 #define PT_BEHIND_SKIP 1   // skip the square root for spheres behind the ray origin

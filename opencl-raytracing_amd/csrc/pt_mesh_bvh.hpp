@@ -36,6 +36,18 @@
 #define PT_MESH_BVH_NONE 0xFFFFFFFFu
 #define PT_MESH_TAU 2.0e-3f
 #define PT_MESH_K 5.0e-6f
+#ifndef PT_MESH_CAP
+#define PT_MESH_CAP 66.0f
+#endif
+#ifndef PT_MESH_SLAB
+#define PT_MESH_SLAB 1  // extra slab test along the projected cone axis for grazing, narrow-cone subtrees
+#endif
+#ifndef PT_MESH_SLAB_SCALE
+#define PT_MESH_SLAB_SCALE 1.0f  // test hook: < 1 must break tests/test_gpu_properties.py::test_mesh_bvh_grazing_rays
+#endif
+#ifndef PT_MESH_SLAB_SIN
+#define PT_MESH_SLAB_SIN 0.5f
+#endif
 
 // MODE 0: search — smallest face index < best_face with a valid front-facing hit.
 // MODE 1: count  — number of faces with index < best_face whose hitTriangle succeeds (any
@@ -91,7 +103,7 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
                 float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;
                 float reach = dfar + 2.0f * ex.z;
                 float m_steep = steep ? PT_MESH_K * reach / (ex.w * cosmin) : INFINITY;
-                float m_cap = capped ? 66.0f * dlen * reach * ex.z * ex.z : INFINITY;
+                float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
                 float m = fminf(m_steep, m_cap) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
                 float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
                 float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
@@ -102,6 +114,21 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
                 // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
                 miss = tmin > tmax + fabsf(tmax) * 1.0e-5f + 1.0e-4f || tmax < -(m + 1.0f) ||
                        tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
+                if (PT_MESH_SLAB && !miss && !steep && ex.x < PT_MESH_SLAB_SIN && sb > 0.5f && ex.w > 1.0e-3f) {
+                    // Grazing subtree with a narrow cone: the displacement m_cap is real, but only ALONG the
+                    // sliver a grazing face projects to.  With barycentrics l_k >= -eta_k (eta_total =
+                    // m_cap / emax) the line's coordinate along any x perpendicular to d leaves the face's
+                    // own extent along x by at most eta_total * (that extent).  Along n' = the part of the
+                    // cone axis perpendicular to d every face of the subtree is thin: an edge e is
+                    // perpendicular to its normal, so |e . n'| <= |e| (sin alpha + |cos psi|) / sin psi.
+                    V3 np = (xyz(cn) - dh * x) * (1.0f / sb);   // |x| <= sin(alpha) + tau here
+                    float hx = 0.5f * (b.x - a.x), hy = 0.5f * (b.y - a.y), hz = 0.5f * (b.z - a.z);
+                    float rn = fabsf(np.x) * hx + fabsf(np.y) * hy + fabsf(np.z) * hz;
+                    float dist = (r.o.x - 0.5f * (a.x + b.x)) * np.x + (r.o.y - 0.5f * (a.y + b.y)) * np.y +
+                                 (r.o.z - 0.5f * (a.z + b.z)) * np.z;
+                    float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) / sb + 1.0e-5f * (dfar + o_max) + 1.0e-5f;
+                    if (fabsf(dist) > rn * 1.0001f + mn) miss = true;
+                }
             }
         }
         bool leaf = (B & 0x80000000u) != 0;

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
         // ---- nearest hit for every lane still active; the table reads of the NEXT material
         // interaction are issued first (they depend on the ray direction only)
         if (active) {
-            if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+            if (PT_RNG_PREFETCH == 1) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
             V3 res;
             bool done = false;
             if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
@@ -408,6 +408,9 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
                 slot[3 * idx + 1] = res.y;
                 slot[3 * idx + 2] = res.z;
                 active = false;
+            } else if (PT_RNG_PREFETCH == 2) {
+                // this lane WILL interact next iteration: its table reads fly during the refill step
+                rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
             }
         }
         PT_STAMP(c, 4);

@@ -335,3 +335,160 @@ def test_mesh_bvh_changes_no_bit(segments, rings, inside, oracle, table):
     assert np.array_equal(out[1][3][:600].view(np.uint32), exp.view(np.uint32))
     assert (out[1][0][..., :3].sum(-1) > 0).mean() > 0.2
     t.close()
+
+
+def _grazing_scene(seed, bump):
+    """A nearly flat, bumpy grid of triangles seen edge-on: every ray grazes hundreds of faces at
+    |cos(theta)| between 1e-6 and a few 1e-2, where the reference's computed barycentrics accept faces
+    far from the ray (the case the mesh BVH's cap and slab margins exist for).  Spacing grows along x so
+    both short-edge (capped) and long-edge (never culled) subtrees occur."""
+    rng = np.random.RandomState(seed)
+    nx, nz = 70, 36
+    xs = np.cumsum(np.linspace(0.04, 0.3, nx + 1)) - 0.5
+    zs = np.linspace(-1.6, 1.6, nz + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = (rng.rand(nx + 1, nz + 1) - 0.5) * 2 * bump
+    pos = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    uv = np.stack([(X - xs[0]) / (xs[-1] - xs[0]), (Z + 1.6) / 3.2], -1).reshape(-1, 2).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nx), np.arange(nz), indexing="ij")
+    v00 = (i * (nz + 1) + j).ravel()
+    v10, v01, v11 = v00 + nz + 1, v00 + 1, v00 + nz + 2
+    flip = rng.rand(len(v00)) < 0.5          # both windings: front- and back-facing hits interleave
+    t1 = np.where(flip[:, None], np.stack([v00, v10, v11], -1), np.stack([v00, v11, v10], -1))
+    t2 = np.where(flip[:, None], np.stack([v00, v11, v01], -1), np.stack([v00, v01, v11], -1))
+    idx = np.stack([t1, t2], 1).reshape(-1).astype(np.uint32)
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.9, 0.6, 0.3), 1)   # 0
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)           # 1
+    s.addMaterial(rt._abi.T_REFLECTIVE, (1, 1, 1), 0.95)   # 2
+    s.addMesh(pos, uv, idx)
+    s.addModel(1, 0)
+    s.addSphere((3, -200, 0), 190, 1)
+    s.addPlane((0, 1.0, 0), (0, 1, 0), 2)
+    return s, len(idx) // 3
+
+
+@pytest.mark.parametrize("seed,bump,height", [(1, 2e-3, -1e-2), (2, 2e-4, -1e-3), (3, 2e-2, -0.1), (4, 1e-5, 2e-4)])
+def test_mesh_bvh_grazing_rays(seed, bump, height):
+    """Mesh BVH against the face scan where it is hardest: rays in (almost) the plane of the faces."""
+    s, faces = _grazing_scene(seed, bump)
+    assert faces > 5000
+    w, h = 96, 64
+    # camera block (Camera::transferData layout): pos, lower-left, horizontal, vertical — a fan of
+    # directions (1, slope, -0.25..0.25) from 4.5 units in front of the grid's first row, the slopes
+    # chosen so that every ray crosses the grid's mean plane somewhere along the grid
+    lo, hi = -height / 16.0, -height / 4.6
+    cam = np.array([-5.0, height, 0.0, 1.0, lo, -0.25, 0.0, 0.0, 0.5, 0.0, hi - lo, 0.0], np.float32)
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    out = []
+    for accel in (0, 1):
+        t.setOption(t.OPT_ACCEL, accel)
+        t.enableCounters(True)
+        t.resetCounters()
+        t.clear()
+        t.renderSamples(cam, 0, 4)
+        lin = t.readLinear()
+        cn = t.counters().as_dict()
+        t.enableCounters(False)
+        t.render(cam)
+        out.append((lin, cn, t.transferImage()))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
+    assert out[0][1] == out[1][1]
+    assert out[0][1]["h_tri"] > 4 * w * h // 2          # the mesh is hit, grazing
+    t.close()
+
+
+def _norm_f32(v):
+    """normalize() of the arithmetic contract on float32 rows: v / sqrt((x·x + y·y) + z·z)."""
+    v = v.astype(np.float32)
+    dd = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+    return (v / np.sqrt(dd)[:, None]).astype(np.float32)
+
+
+def _displaced_acceptance_scene(edge):
+    """48 isolated target quads (96 faces with the LOWEST face indices of the mesh, so an accepted target
+    wins the reference's first-hit-in-face-order rule) followed by a bumpy filler grid that gives the
+    BVH depth."""
+    rng = np.random.RandomState(5)
+    pos, idx = [], []
+    for k in range(48):
+        c = np.array([(k % 8) * 0.7 - 2.4, rng.uniform(-2e-3, 2e-3), (k // 8) * 0.7 - 1.7])
+        a = rng.uniform(0, 2 * np.pi)
+        e1 = edge * np.array([np.cos(a), rng.uniform(-2e-3, 2e-3), np.sin(a)])
+        e2 = edge * rng.uniform(0.6, 1.0) * np.array([-np.sin(a), rng.uniform(-2e-3, 2e-3), np.cos(a)])
+        base = len(pos)
+        pos += [c, c + e1, c + e2, c + e1 + e2]      # a small quad = two faces = one tight BVH leaf
+        idx += [base, base + 1, base + 2, base + 1, base + 3, base + 2]
+    n = 40
+    gx, gz = np.meshgrid(np.linspace(-3, 3, n + 1), np.linspace(-2.5, 2.5, n + 1), indexing="ij")
+    gy = 0.6 + rng.uniform(-0.02, 0.02, gx.shape)
+    base = len(pos)
+    pos += list(np.stack([gx, gy, gz], -1).reshape(-1, 3))
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    v00 = (base + i * (n + 1) + j).ravel()
+    quads = np.stack([v00, v00 + n + 2, v00 + n + 1, v00, v00 + 1, v00 + n + 2], -1)
+    idx += list(quads.reshape(-1))
+    # a generic orientation: with axis-aligned faces the products of s·(d×e2) are tiny and so are
+    # their rounding errors; tilted, the three products are large and cancel
+    q, _ = np.linalg.qr(np.random.RandomState(9).randn(3, 3))
+    pos = (np.asarray(pos) @ q.T).astype(np.float32)
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.9, 0.6, 0.3), 1)
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)
+    s.addMesh(pos, np.zeros((len(pos), 2), np.float32), np.asarray(idx, np.uint32))
+    s.addModel(1, 0)
+    s.addSphere(tuple(q @ np.array([0.0, -200.0, 0.0])), 190, 1)
+    return s, pos.astype(np.float64), np.asarray(idx[:96 * 3]).reshape(96, 3)
+
+
+@pytest.mark.parametrize("edge", [0.1, 0.18])
+def test_mesh_bvh_keeps_faces_accepted_far_from_the_ray(edge, oracle):
+    """At |cos(theta)| ~ 1e-5 the reference's binary32 Möller–Trumbore accepts faces whose geometric
+    position is several edge lengths away from the ray (the errors grow with the distance of the
+    origin).  Such rays are found here with the oracle's hitTriangle, made the (only) primary ray of a
+    tiny frame, and the mesh BVH must still agree bit for bit with the face scan.  (A build with
+    -DPT_MESH_CAP=0.2f, the cap margin at 0.003 of its value, fails this test.)"""
+    s, pos, tri = _displaced_acceptance_scene(edge)
+    rng = np.random.RandomState(11)
+    n = 600000
+    f = rng.randint(0, 96, n)
+    A, B, Cc = pos[tri[f, 0]], pos[tri[f, 1]], pos[tri[f, 2]]
+    nrm = np.cross(B - A, Cc - A)
+    area2 = np.linalg.norm(nrm, axis=1)
+    nrm /= area2[:, None]
+    a = rng.uniform(0, 2 * np.pi, n)
+    t1 = (B - A) / np.linalg.norm(B - A, axis=1)[:, None]
+    t2 = np.cross(nrm, t1)
+    w = np.cos(a)[:, None] * t1 + np.sin(a)[:, None] * t2                   # in-plane direction
+    c = (1.0e-7 / area2) * rng.uniform(0.9, 3.0, n)                        # |cos(theta)|: |a| just above the epsilon
+    d = w * np.sqrt(1 - c * c)[:, None] - nrm * c[:, None]                  # front-facing: n·d < 0
+    long_axis = np.cross(d, nrm)                                            # the sliver's long axis
+    delta = 10.0 ** rng.uniform(-1.0, 0.0, n) * rng.choice([-1.0, 1.0], n)
+    centroid = (A + B + Cc) / 3
+    o = centroid + long_axis * delta[:, None] - d * rng.uniform(30, 90, n)[:, None]
+    v = d.astype(np.float32)
+    rays = np.concatenate([o.astype(np.float32), _norm_f32(v)], 1)
+    hit = oracle.hit_triangle(s, rays, np.zeros(n, np.uint32), f.astype(np.uint32))[:, 0] > 0
+    far = np.abs(delta) > 1.5 * edge          # the line passes the centroid at > 1.5 edge lengths
+    pick = np.nonzero(hit & far)[0]
+    assert len(pick) >= 12, len(pick)
+    pick = pick[np.argsort(-np.abs(delta[pick]))][:48]
+    t = rt.RayTracer(4, 4, scene=s, seed=cases.SEED)
+    found = 0
+    for k in pick:
+        cam = np.concatenate([rays[k, :3], v[k], np.zeros(6, np.float32)]).astype(np.float32)
+        out = []
+        for accel in (0, 1):
+            t.setOption(t.OPT_ACCEL, accel)
+            t.enableCounters(True)
+            t.resetCounters()
+            t.clear()
+            t.renderSamples(cam, 0, 2)
+            out.append((t.readLinear(), t.counters().as_dict()))
+            t.enableCounters(False)
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), (k, delta[k], c[k])
+        assert out[0][1] == out[1][1], (k, delta[k], c[k])
+        found += out[0][1]["h_tri"] > 0
+    assert found >= len(pick) // 2
+    t.close()
