@@ -2,7 +2,7 @@
 // Binned-SAH splits over face centroids, leaves of <= 4 faces; children in adjacent pairs (left at
 // an odd global index, every tree starts at an even index); per node: bounds, parent, split axis,
 // normal cone (axis, cos/sin of the half angle, widened by 1e-4 rad), smallest face index, longest
-// edge and the smallest sin(angle between the two edges) of the subtree.
+// edge and the smallest quality q = sin(angle between the two edges) · shape factor of the subtree.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -25,7 +25,7 @@ struct MeshBvhBuilder {
     std::vector<uint32_t> order;
     std::vector<float> lo, hi, cen;  // 3 per face
     std::vector<double> nrm;         // 3 per face (unit, or 0 for degenerate)
-    std::vector<float> qual;         // sin(phi) per face
+    std::vector<float> qual;         // sin(phi) · shape factor per face (0 = degenerate)
     std::vector<float> elen;         // longest of |e1|, |e2|, |e2 - e1| per face
 
     void prepare() {
@@ -51,9 +51,14 @@ struct MeshBvhBuilder {
             double l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
             bool ok = std::isfinite(cl) && cl > 0 && l1 > 0 && l2 > 0;
             for (int k = 0; k < 3; k++) nrm[3 * f + k] = ok ? c[k] / cl : 0.0;
-            qual[f] = ok ? (float)(cl / (l1 * l2)) : 0.0f;
             double d3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
             double l3 = std::sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+            // shape factor of the "steep" margin (pt_mesh_bvh.hpp): the corners of the region the reference
+            // accepts lie within u·G·|s| / (sin(phi)·|cos(theta)|) of the face, G = 16.9 at A and
+            // 8.25 + 8.66 (|e1|+|e3|)/|e2| resp. 8.66 + 8.25 (|e2|+|e3|)/|e1| at B and C (needles are worse);
+            // q = sin(phi) · 25.6 / G  (25.6 = G of an equilateral face)
+            double G = ok ? std::max(16.9, std::max(8.25 + 8.66 * (l1 + l3) / l2, 8.66 + 8.25 * (l2 + l3) / l1)) : 1.0;
+            qual[f] = ok ? (float)(cl / (l1 * l2) * 25.6 / G) : 0.0f;
             elen[f] = (float)(std::max(l1, std::max(l2, l3)) * 1.0001);
         }
     }

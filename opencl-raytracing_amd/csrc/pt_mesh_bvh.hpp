@@ -7,25 +7,34 @@
 // faces — provided it never drops a face the reference would have accepted.
 //
 // Why culling is safe (DESIGN.md "mesh BVH").  hitTriangle is Möller–Trumbore in
-// binary32 (:257-289); it is invariant to the length of the direction.  Let X be the
-// exact intersection of the ray's LINE with the face's plane.  Forward error analysis
-// of (a, u, v) gives: if the computed (u, v) pass the reference's tests, X lies within
-//     rho = 1.1e-6 · (|s| + |e1| + |e2|) / (sin(phi) · |cos(theta)|)
-// of the triangle (u = 2^-24; s = origin − A; phi = angle between the edges; theta =
-// angle between the direction and the face normal), as long as |cos(theta)| is not at
-// the noise level.  So a node may be skipped when the line misses its box inflated by
-// rho evaluated with the node's worst case: |s| <= dfar (largest distance origin → box),
-// |e| <= box diagonal, sin(phi) >= q (smallest over the subtree), |cos(theta)| >= the
-// minimum over the subtree's NORMAL CONE — and it is never skipped (only index-pruned)
-// when that minimum is below TAU (the ray may graze some face of the subtree: the
-// computed barycentrics of such a face are unreliable far from it) — except through the
-// cap that the reference's own rejection |a| < TRIANGLE_EPSILON provides: an accepted face
-// has |a_computed| >= 1e-7, and for edges short enough that the rounding error of a stays
-// below half of that (emax² <= 0.04/|d|), |a| >= 0.5e-7 bounds the displacement by
-// rho_cap = 66·|d|·(|s| + 2·emax)·emax² whatever the angle.  K below carries a 4x safety
-// factor, the cap 1.5x.  Candidates are tested with the very same triangle_t() and the
-// very same precomputed normal as the brute-force scan, so a visited face gives the
-// reference's verdict bit for bit.
+// binary32 (:257-289), every operation rounded once (no FMA), u = 2^-24.  Forward error
+// analysis of its three numerators against the exact values for the stored vertices:
+//     |δa|  <= 8.25 u |d| |e1| |e2|        a  = e1 · (d × e2)
+//     |δnu| <= 8.25 u |s| |d| |e2|         nu = s · (d × e2),  s = origin − A
+//     |δnv| <= 8.66 u |s| |d| |e1|         nv = d · (s × e1)
+// A face the reference accepts therefore has exact barycentrics (of the point where the
+// ray's LINE meets the face's plane; equivalently of the line seen along d) with
+//     l_B >= −|δnu|/|a|,  l_C >= −|δnv|/|a|,  l_A >= −(|δnu| + |δnv| + |δa|)/|a| − 4u.
+// Three margins follow, all used below with |s| <= reach = dfar + 2·emax (dfar = largest
+// distance origin → node box, emax = longest edge of the subtree):
+//  steep   |a| = |d| |e1| |e2| sin(phi) |cos(theta)|: the accepted region is the face grown by at most
+//          u·G·|s| / (sin(phi)·|cos(theta)|), G a shape factor (25.6 equilateral; mesh_bvh_build.hpp).
+//          m_steep = K·reach / (q·cosmin), q = min sin(phi)·25.6/G over the subtree, cosmin = the
+//          smallest |cos(theta)| over the subtree's NORMAL CONE; K = 5e-6 = 3.3 × 25.6 u.  Only when
+//          cosmin > TAU and q > 1e-3 (then |δa| << |a| and the sign of a is right).
+//  cap     the reference rejects |a_computed| < 1e-7 (TRIANGLE_EPSILON), so for emax²·|d| <= 0.04
+//          (|δa| <= 0.2e-7) every accepted face has |a| >= 0.8e-7 whatever the angle, the negative
+//          barycentrics sum to at most N = 19.0·|d|·reach·emax, and the line passes within N·emax of
+//          the face.  m_cap = PT_MESH_CAP·|d|·reach·emax², PT_MESH_CAP = 40 (2.1 × 19.0).
+//  slab    same N, but along a direction x perpendicular to d the line leaves the face's own extent
+//          along x by at most N·(that extent): grazing faces are thin along the part of the cone axis
+//          perpendicular to d, which removes the "silhouette band" (see the code).
+// A node is skipped when the line misses its box inflated by min(m_steep, m_cap) or fails the slab
+// test; with neither steep nor cap it is only index-pruned.  Candidates are tested with the very
+// same triangle_t() and the very same precomputed normal as the brute-force scan, so a visited
+// face gives the reference's verdict bit for bit.
+// tests/test_gpu_properties.py::test_mesh_bvh_keeps_faces_accepted_far_from_the_ray drives rays the
+// reference accepts 2–5 edge lengths away from the face through this walk.
 //
 // Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
 //   A = parent | split_axis << 28;  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
@@ -37,7 +46,7 @@
 #define PT_MESH_TAU 2.0e-3f
 #define PT_MESH_K 5.0e-6f
 #ifndef PT_MESH_CAP
-#define PT_MESH_CAP 66.0f
+#define PT_MESH_CAP 40.0f
 #endif
 #ifndef PT_MESH_SLAB
 #define PT_MESH_SLAB 1  // extra slab test along the projected cone axis for grazing, narrow-cone subtrees
@@ -94,7 +103,7 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
             float x = dot(dh, xyz(cn));
             float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
             float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
-            bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-6f;    // no face of the subtree can be grazed
+            bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-3f;    // no face of the subtree can be grazed
             bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
             if (steep || capped) {
                 float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
