@@ -1,0 +1,55 @@
+"""bench.py's contract on the GPU box: the one-GPU line with `roofline`, `parity` and `cpu_baseline`,
+and the N > 1 launch rehearsed with two ranks sharing the one GPU (gloo moves the buffers — RCCL
+refuses two ranks on one device; the kernels, sharding, packing and timing code are the real ones)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_one_gpu_line():
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-budget", "2"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _json_line(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "Msamples/s"
+    assert j["config"]["pixel_samples_per_step"] == 1920 * 1080 * 64
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    # the step is the launch plus clear + resolve: the wall clock per step cannot be below the kernel time
+    assert j["ms_per_step"] >= r["kernel_ms"] * 0.98
+    assert abs(j["value"] - j["config"]["pixel_samples_per_step"] / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
+    assert j["parity"]["bit_exact"] == j["parity"]["probes"] > 0
+    c = j["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("reference", "port")
+    assert j["value"] > 100 * c["value"]
+
+
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
+def test_bench_two_ranks_share_the_gpu(exchange):
+    env = dict(os.environ, RT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--exchange", exchange]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = _json_line(p.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["spp_total"] == 128 and j["config"]["pixel_samples_per_step"] == 1920 * 1080 * 128
+    assert "cpu_baseline" not in j          # rank 0 at N = 1 only
+    assert j["value"] > 0
