@@ -53,3 +53,13 @@ def test_bench_two_ranks_share_the_gpu(exchange):
     assert j["config"]["spp_total"] == 128 and j["config"]["pixel_samples_per_step"] == 1920 * 1080 * 128
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
     assert j["value"] > 0
+
+
+def test_sharded_frame_equals_unsharded_frame():
+    """Three ranks on the one GPU (gloo): tile-sharded render + exchange == the unsharded render."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "SHARDED_OK gather" in p.stdout and "SHARDED_OK reduce" in p.stdout
