@@ -509,7 +509,9 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         if (!brute) hit_spheres_bvh<COUNT>(sc, r, best_t, best_id, c.cn);
     }
     // brute force: wave-uniform index → scalar loads; a batch of 4 in flight while 4 are tested
+#ifndef PT_QSTAT
     if (COUNT && brute) c.cn->c[CN_DBG_BVH_TESTS] += sc.sphere_count;
+#endif
     if (brute && sc.sphere_batches) {
         const float4 *sp = (PT_LDS_SPHERES && c.lsph) ? c.lsph : sc.sph4;
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];

@@ -370,6 +370,13 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
             continue;  // every candidate was a final-colour pixel: keep draining the queue
         }
         PT_STAMP(c, 0);
+#ifdef PT_QSTAT  // diagnostic: lane-iterations used / offered (read through rt_get_debug_counters on a BVH-free scene)
+        if (COUNT) {
+            uint32_t na = (uint32_t)__popcll(__ballot(active));
+            if (lane == 0) cn.c[CN_DBG_BVH_NODES] += na;
+            if (lane == 0) cn.c[CN_DBG_BVH_TESTS] += 64u;
+        }
+#endif
         // ---- one material interaction for every active lane
         if (active) {
             if (!PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);

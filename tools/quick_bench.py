@@ -8,6 +8,9 @@ import opencl_raytracing_amd as rt
 args = sys.argv[1:]
 if args and args[0].startswith("--lib="):
     rt.load_library(args.pop(0)[6:])
+queue = None
+if args and args[0].startswith("--queue="):
+    queue = int(args.pop(0)[8:])
 for spec in args:
     parts = spec.split(":")
     name, spp = parts[0], int(parts[1])
@@ -16,6 +19,8 @@ for spec in args:
         kw = dict(width=int(parts[2]), height=int(parts[3]))
     wl = rt.workloads.get(name, **kw)
     t = rt.RayTracer(wl.width, wl.height, scene=wl.scene)
+    if queue is not None:
+        t.setOption(t.OPT_SAMPLE_QUEUE, queue)
     t.clear(); t.renderSamples(wl.camera, 0, spp); t.sync()
     ms = []
     for _ in range(3):
