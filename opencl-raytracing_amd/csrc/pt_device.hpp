@@ -274,6 +274,9 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float dis = b * b - cc;
     return sphere_root(b, cc, dis);
 }
+#ifndef PT_SPHERE_ROUNDS
+#define PT_SPHERE_ROUNDS 0  // A/B: 1 = small scenes record a candidate mask first and take the square roots in per-lane rounds; no gain measured
+#endif
 #ifndef PT_BATCH_ROOTS
 #define PT_BATCH_ROOTS 0  // A/B: 1 = the square-root path of a sphere batch runs once per ROUND (lanes pick their
 #endif                    // first candidate) instead of once per sphere with a handful of lanes active; no gain measured
@@ -512,6 +515,42 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
 #ifndef PT_QSTAT
     if (COUNT && brute) c.cn->c[CN_DBG_BVH_TESTS] += sc.sphere_count;
 #endif
+    if (PT_SPHERE_ROUNDS && brute && sc.sphere_count <= 32u && c.lwin) {
+        // Two passes.  The square-root path of a sphere is needed by the few lanes whose ray meets it, but
+        // a wave runs it whenever ANY lane does — on C2 that is nearly every sphere of every bounce, at
+        // ~5 % lane utilisation.  Pass 1 only records, per lane, WHICH spheres need their roots (the same
+        // discriminant arithmetic, 20 instructions per sphere); pass 2 runs rounds in which every lane
+        // works on its own next candidate (record from LDS), in index order with the reference's strict '<':
+        // as many rounds as the busiest lane has candidates (2-3) instead of one root block per sphere.
+        uint32_t cand = 0;
+        const float4 *sp = sc.sph4;
+        float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
+        for (uint32_t b = 0; b < sc.sphere_batches; b++) {
+            sp += PT_SPHERE_BATCH;
+            float4 n0_ = sp[0], n1_ = sp[1], n2_ = sp[2], n3_ = sp[3];
+            float bb, cc, dd;
+            sphere_disc(r, a0, bb, cc, dd);
+            uint32_t m = sphere_needs_roots(bb, cc, dd) ? 1u : 0u;
+            sphere_disc(r, a1, bb, cc, dd);
+            m |= sphere_needs_roots(bb, cc, dd) ? 2u : 0u;
+            sphere_disc(r, a2, bb, cc, dd);
+            m |= sphere_needs_roots(bb, cc, dd) ? 4u : 0u;
+            sphere_disc(r, a3, bb, cc, dd);
+            m |= sphere_needs_roots(bb, cc, dd) ? 8u : 0u;
+            cand |= m << (b * PT_SPHERE_BATCH);
+            a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
+        }
+        while (__any(cand != 0u)) {
+            if (cand) {
+                uint32_t j = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                float4 w = c.lwin[2 * j];
+                float t = sphere_t(r, make_float4(w.x, w.y, w.z, w.w * w.w));  // r·r: the product the host stored in sph4
+                if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | j; }
+            }
+        }
+        brute = false;
+    }
     if (brute && sc.sphere_batches) {
         const float4 *sp = (PT_LDS_SPHERES && c.lsph) ? c.lsph : sc.sph4;
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
