@@ -25,6 +25,28 @@ def test_abi_exports_every_declared_symbol(built):
     assert lib.rt_abi_version() == 1
 
 
+def test_header_is_plain_c_and_a_c_program_links(built, tmp_path):
+    """include/rt_amd.h is a C99 header (no C++, no torch types) and a C caller links against the library."""
+    import subprocess
+    src = tmp_path / "caller.c"
+    src.write_text('#include <stdio.h>\n#include "rt_amd.h"\n'
+                   'int main(void) {\n'
+                   '    rt_context *ctx = NULL;\n'
+                   '    rt_scene_desc d = {0};\n'
+                   '    (void)d;\n'
+                   '    printf("%d %zu %zu %zu\\n", rt_abi_version(), sizeof(rt_sphere), sizeof(rt_material), sizeof(rt_counters));\n'
+                   '    return rt_render(ctx, NULL) == RT_OK;   /* a NULL context is an error, not a crash */\n'
+                   '}\n')
+    exe = tmp_path / "caller"
+    pkg = os.path.dirname(rt.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", pkg, "-lrt_amd", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "32", "48", "112"]
+
+
 def test_struct_layouts_match_reference_device_structs():
     a = rt._abi
     assert (a.MATERIAL.itemsize, a.SPHERE.itemsize, a.PLANE.itemsize, a.LENS.itemsize, a.MESH.itemsize,
