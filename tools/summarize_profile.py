@@ -20,7 +20,16 @@ KERNELS = (sys.argv[3] if len(sys.argv) > 3 else "pt_prefix<false, false>;pt_sam
 KERNEL = " + ".join(KERNELS)
 
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern, window=1200.0):
+    """gpurun merges every call's files into the same directory: keep those of the latest run only."""
+    files = glob.glob(pattern)
+    if not files:
+        return []
+    last = max(os.path.getmtime(f) for f in files)
+    return sorted(f for f in files if last - os.path.getmtime(f) <= window)
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"), 60.0)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
@@ -38,7 +47,7 @@ if os.path.isfile(bench) and os.path.getsize(bench):
               (b["value"], b["unit"], b["roofline"]["kernel_ms"], b["roofline"]["frac"]), ""]
 
 per_kernel = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
             if k in r["Kernel_Name"]:
