@@ -63,3 +63,12 @@ def test_sharded_frame_equals_unsharded_frame():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "SHARDED_OK gather" in p.stdout and "SHARDED_OK reduce" in p.stdout
+
+
+def test_rccl_accepts_the_collectives_of_the_exchange():
+    """World size 1 over RCCL (backend "nccl"): the gather / reduce / barrier calls ShardedRenderer issues,
+    on a non-default stream, are accepted by this image's torch + RCCL."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_selftest.py")], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    assert "RCCL world-1 gather/reduce/barrier OK nccl" in p.stdout
