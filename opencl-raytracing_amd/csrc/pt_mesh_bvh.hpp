@@ -48,6 +48,9 @@
 #ifndef PT_MESH_CAP
 #define PT_MESH_CAP 40.0f
 #endif
+#ifndef PT_MESH_BACKFACE_CULL
+#define PT_MESH_BACKFACE_CULL 1
+#endif
 #ifndef PT_MESH_SLAB
 #define PT_MESH_SLAB 1  // extra slab test along the projected cone axis for grazing, narrow-cone subtrees
 #endif
@@ -104,8 +107,20 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
             float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
             float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
             bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-3f;    // no face of the subtree can be grazed
+            // search mode wants FRONT-facing hits only (dot(n, d) < 0, :298): a subtree whose whole normal
+            // cone points along the ray (n·d̂ >= cos(psi + alpha) > 0, far above the rounding of the
+            // reference's own dot product) holds back faces only — the exit side of a closed mesh
+#ifdef PT_MESH_STAT  // diagnostic: which kind of node is entered (read through the face-test debug counter)
+            if (dbg) {
+                bool wide = ex.x >= PT_MESH_SLAB_SIN;
+                int kind = wide ? 1 : (steep ? 3 : 2);
+                if (kind == PT_MESH_STAT) dbg->c[CN_DBG_BVH_TESTS]++;
+            }
+#endif
+            bool backside = MODE == 0 && PT_MESH_BACKFACE_CULL && x * cn.w - sb * ex.x > 1.0e-3f;
+            if (backside) miss = true;
             bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
-            if (steep || capped) {
+            if (!backside && (steep || capped)) {
                 float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
                 float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
                 float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
@@ -148,7 +163,9 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
                 if (idx >= best_face) continue;
                 const float4 *fq = sc.mbvh_faces + 3 * (size_t)(first + k);
                 float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
+#ifndef PT_MESH_STAT
                 if (dbg) dbg->c[CN_DBG_BVH_TESTS]++;
+#endif
                 float u, v;
                 float t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
                 if (t > 0.0f) {
