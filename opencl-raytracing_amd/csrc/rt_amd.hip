@@ -166,9 +166,11 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     uint32_t x = 0, y = 0;
     bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
     bool is_live = false;
+    PixelRec rec;
+    rec.p_kind = rec.n_extra = rec.d = rec.out = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (valid) {
         Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
-        PixelRec rec = trace_prefix<COUNT, ACCEL>(c, r0, x, y);
+        rec = trace_prefix<COUNT, ACCEL>(c, r0, x, y);
         uint32_t g = 1u << fp.group_log2;
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         if (final_px && (fp.count & (g - 1u)) == 0) {
@@ -178,18 +180,22 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
             accumulate(accum, (size_t)y * fp.w + x, sum, fp.count);
             if (COUNT) cn.c[CN_SAMPLES] += 1;  // scaled by count below
         } else {
-            recs[slot] = rec;
             is_live = true;
         }
     }
-    // append live slots: one atomic per wave (order is irrelevant to the result)
+    // append live pixels — slot index and record, both at the pixel's position in the live list, so the
+    // sample kernels read records without an indirection: one atomic per wave (order is irrelevant to the result)
     unsigned long long m = __ballot(is_live);
     if (m) {
         uint32_t lane = threadIdx.x & 63u, n = (uint32_t)__popcll(m);
         uint32_t base = 0;
         if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(live_count, n);
         base = __shfl(base, __ffsll((long long)m) - 1);
-        if (is_live) live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+        if (is_live) {
+            uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            live[pos] = slot;
+            recs[pos] = rec;
+        }
     }
     flush_counters<COUNT>(cn, counters, fp.count);  // the prefix stands for `count` samples' worth of work
 }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
     if (valid) {
         uint32_t slot = live[li];
         (void)slot_to_pixel(fp, slot, x, y);
-        PixelRec rec = recs[slot];
+        PixelRec rec = recs[li];
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     // stage this wave's pixel records and coordinates
     for (uint32_t i = lane; i < npix * 5u; i += 64u) {
         uint32_t p = i / 5u, part = i - p * 5u;
-        s_rec[i] = reinterpret_cast<const float4 *>(recs + live[pix0 + p])[part];
+        s_rec[i] = reinterpret_cast<const float4 *>(recs + pix0 + p)[part];
     }
     if (lane < npix) {
         uint32_t x = 0, y = 0;
