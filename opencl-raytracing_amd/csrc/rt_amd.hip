@@ -451,240 +451,6 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     flush_counters<COUNT>(cn, counters, 1);
 }
 
-// pt_samples_r — the sample queue over a RING of pixel slots.  pt_samples_q gives a wave one batch
-// of P pixels; while the last, long paths of the batch finish, idle lanes have nothing to pull (the
-// queue's tail: 14 % of the lane-iterations at 64 spp, 25 % at 16 spp).  Here the wave is persistent
-// and streams pixels gwave, gwave + n_waves, … of the live list through the same P LDS slots: a slot
-// is summed (same fixed order → still bit-identical) and reused as soon as the last sample of ITS
-// pixel retires, whatever the other pixels do, so a straggler holds one slot, not the wave.
-//   per slot   record (80 B) · coordinates · retired-sample counter (LDS atomic) · 12 B per sample
-//   wave state free-slot mask, FIFO of loaded slots (4-bit ids packed in 64 bits), fully-issued mask
-//   loading    up to 8 pixels per iteration, two-phase: global loads into registers in iteration i,
-//              LDS stores in iteration i + 1 (the latency hides behind a whole iteration)
-// Every wave-level decision is wave-uniform (ballots, scalar masks); no inter-wave communication.  The
-// loop ends when the stream is exhausted and every slot has been summed; a hard bound guarantees it.
-#define RING_GROUPS 8
-__host__ __device__ inline uint32_t ring_wave_lds_bytes(uint32_t P, uint32_t count) {
-    uint32_t b = P * 5u * 16u + P * 2u * 4u + ((P + 3u) & ~3u) * 4u + P * count * 3u * 4u;
-    return (b + 15u) & ~15u;
-}
-template <bool COUNT, bool ACCEL>
-__global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_r(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
-                                                    const uint32_t *__restrict__ live,
-                                                    const uint32_t *__restrict__ live_count,
-                                                    float4 *__restrict__ accum, unsigned long long *counters,
-                                                    uint32_t P) {
-    extern __shared__ float4 s_dyn[];
-    float4 *s_mat = s_dyn;
-    LaneCounters cn;
-    if (COUNT) zero_counters(cn);
-    Ctx c{sc, stage_materials(sc, s_mat), &cn};
-    c.lwin = staged_winners(sc, s_mat);
-    c.lpln = staged_planes(sc, s_mat);
-
-    // the wave index is wave-uniform, which the compiler cannot see: everything derived from it goes to SGPRs
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    const uint32_t count = fp.count;
-    char *wl = reinterpret_cast<char *>(s_dyn + PT_LDS_STATIC_FLOAT4) + (size_t)wave * ring_wave_lds_bytes(P, count);
-    float4 *s_rec = reinterpret_cast<float4 *>(wl);
-    uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + P * 5u);
-    uint32_t *s_ret = s_xy + P * 2u;
-    float *s_slot = reinterpret_cast<float *>(s_ret + ((P + 3u) & ~3u));
-    const uint32_t n_live = *live_count;
-    const uint32_t gwave = blockIdx.x * 4u + wave, n_waves = gridDim.x * 4u;
-    if (gwave >= n_live) return;  // (whole wave)
-    const uint32_t s_end = (n_live - gwave + n_waves - 1u) / n_waves;  // pixels in this wave's stream
-    uint32_t s_next = 0;                                               // next stream pixel to load
-    if (lane < P) s_ret[lane] = 0u;
-    uint32_t free_mask = (1u << P) - 1u, issued_mask = 0u;  // wave-uniform
-    unsigned long long fifo = 0ull;                         // loaded slots in issue order, 4 bits each
-    uint32_t fifo_len = 0u, cur_j = 0u;                     // cur_j: samples already issued from the FIFO's head
-    uint32_t pf_n = 0u;                                     // pixels whose loads are in flight ...
-    unsigned long long pf_fifo = 0ull;                      // ... and their slots
-    float4 pf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t pf_q = 0u;
-
-    const float inv_count = 1.0f / (float)count;
-    const uint32_t g = 1u << fp.group_log2;
-    bool active = false;
-    uint32_t sidx = 0, dq = 0, gx = 0, gy = 0;  // sidx: sample slot (q·count + j); dq: depth | q << 8
-    int type = 0;
-    float extra = 0.0f;
-    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);
-    Ray r;
-    r.o = r.d = mk(0.0f, 0.0f, 0.0f);
-    Hit h;
-    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
-    h.u = h.v = 0.0f;
-    h.tex = h.mat = 0;
-    Rnd rnd;
-
-    // every iteration retires or advances a lane by one bounce, or moves a pixel through the ring
-    for (unsigned long long guard = (unsigned long long)s_end * ((unsigned long long)count * (RT_DEPTH + 2u) + 16u) + 64u; guard; guard--) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- (1) pixels whose samples have all retired: sum in pt_render's order, free the slot
-        if (issued_mask) {
-            uint32_t rv = lane < P ? s_ret[lane] : 0u;
-            unsigned long long done = __ballot(lane < P && ((issued_mask >> lane) & 1u) != 0u && rv == count);
-            while (done) {
-                uint32_t q = (uint32_t)__builtin_ctzll(done);
-                done &= done - 1ull;
-                const float *sl = s_slot + (size_t)q * count * 3u;
-                V3 sum = mk(0.0f, 0.0f, 0.0f);
-                if (lane < g)
-                    for (uint32_t j = lane; j < count; j += g) sum = sum + mk(sl[3u * j], sl[3u * j + 1u], sl[3u * j + 2u]);
-                sum = group_sum(sum, g);
-                if (lane == 0) {
-                    accumulate(accum, (size_t)s_xy[2u * q + 1u] * fp.w + s_xy[2u * q], sum, count);
-                    s_ret[q] = 0u;
-                }
-                issued_mask &= ~(1u << q);
-                free_mask |= 1u << q;
-            }
-        }
-        // ---- (2a) records requested in the previous iteration: registers → LDS, slots → FIFO
-        if (pf_n) {
-            uint32_t grp = lane >> 3, part = lane & 7u;
-            if (grp < pf_n) {
-                if (part < 5u) s_rec[pf_q * 5u + part] = pf;
-                else if (part == 5u) {
-                    uint32_t x = 0, y = 0;
-                    (void)slot_to_pixel(fp, __float_as_uint(pf.x), x, y);
-                    s_xy[2u * pf_q] = x;
-                    s_xy[2u * pf_q + 1u] = y;
-                }
-            }
-            fifo |= pf_fifo << (4u * fifo_len);
-            fifo_len += pf_n;
-            pf_n = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- (2b) request the next pixels of the stream into free slots (up to 8: lane group → pixel); the data
-        // is stored to LDS one iteration later, so the load latency hides behind a whole iteration
-        if (free_mask && s_next < s_end) {
-            uint32_t n = min(min((uint32_t)__popc(free_mask), (uint32_t)RING_GROUPS), s_end - s_next);
-            uint32_t grp = lane >> 3, part = lane & 7u;
-            uint32_t fm = free_mask;
-            for (uint32_t i = 0; i < grp && i < n; i++) fm &= fm - 1u;  // this group's free slot: the grp-th set bit
-            pf_q = (uint32_t)__builtin_ctz(fm | 0x80000000u);
-            if (grp < n) {
-                size_t s = (size_t)gwave + (size_t)(s_next + grp) * n_waves;
-                if (part < 5u) pf = reinterpret_cast<const float4 *>(recs + s)[part];
-                else if (part == 5u) pf.x = __uint_as_float(live[s]);
-            }
-            pf_fifo = 0ull;
-            for (uint32_t i = 0; i < n; i++) {  // wave-uniform: the n lowest free slots, in order
-                pf_fifo |= (unsigned long long)__builtin_ctz(free_mask) << (4u * i);
-                free_mask &= free_mask - 1u;
-            }
-            s_next += n;
-            pf_n = n;
-        }
-        // ---- (3) refill idle lanes from the FIFO
-        {
-            bool need = !active;
-            unsigned long long m = __ballot(need);
-            uint32_t avail = fifo_len * count - cur_j;
-            if (m && avail) {
-                uint32_t k = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (need && k < avail) {
-                    uint32_t jj = cur_j + k;
-                    // d = jj / count exactly (see pt_samples_q; jj < 16·512 + 64)
-                    uint32_t d = (uint32_t)(((float)jj + 0.5f) * inv_count);
-                    uint32_t j = jj - d * count;
-                    uint32_t lq = (uint32_t)(fifo >> (4u * d)) & 15u;
-                    sidx = lq * count + j;
-                    float4 q0 = s_rec[5u * lq], q1 = s_rec[5u * lq + 1u], q2 = s_rec[5u * lq + 2u], q3 = s_rec[5u * lq + 3u],
-                           q4 = s_rec[5u * lq + 4u];
-                    gx = s_xy[2u * lq];
-                    gy = s_xy[2u * lq + 1u];
-                    uint32_t bits = __float_as_uint(q0.w);
-                    if (COUNT) cn.c[CN_SAMPLES]++;
-                    if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
-                        s_slot[3u * sidx] = q3.x;
-                        s_slot[3u * sidx + 1u] = q3.y;
-                        s_slot[3u * sidx + 2u] = q3.z;
-                        atomicAdd(&s_ret[lq], 1u);
-                    } else {
-                        dq = ((bits >> 8) & 0xFFu) | (lq << 8);
-                        type = (int)(bits >> 16);
-                        h.p = xyz(q0);
-                        h.n = xyz(q1);
-                        extra = q1.w;
-                        r.o = xyz(q0);
-                        r.d = xyz(q2);
-                        h.mat = __float_as_uint(q2.w);
-                        out = xyz(q3);
-                        col = xyz(q4);
-                        active = true;
-                    }
-                }
-                cur_j += min((uint32_t)__popcll(m), avail);
-                while (fifo_len && cur_j >= count) {  // the head pixel is fully issued
-                    issued_mask |= 1u << ((uint32_t)fifo & 15u);
-                    fifo >>= 4;
-                    fifo_len--;
-                    cur_j -= count;
-                }
-            }
-        }
-        if (!__any(active)) {
-            if (s_next >= s_end && pf_n == 0u && fifo_len == 0u && issued_mask == 0u) break;
-            continue;
-        }
-#ifdef PT_QSTAT
-        if (COUNT) {
-            uint32_t na = (uint32_t)__popcll(__ballot(active));
-            if (lane == 0) cn.c[CN_DBG_BVH_NODES] += na;
-            if (lane == 0) cn.c[CN_DBG_BVH_TESTS] += 64u;
-        }
-#endif
-        // ---- (4) one material interaction for every active lane
-        if (active) {
-            const uint32_t lq = dq >> 8, depth = dq & 0xFFu;
-            rnd = fetch_rnd(sc.table, r.d, depth + fp.first + (sidx - lq * count), gx, gy);
-            scatter<COUNT>(c, r, out, h, type, extra, col, rnd);
-            dq++;
-            if (depth + 1u >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
-                s_slot[3u * sidx] = out.x;
-                s_slot[3u * sidx + 1u] = out.y;
-                s_slot[3u * sidx + 2u] = out.z;
-                atomicAdd(&s_ret[lq], 1u);
-                active = false;
-            }
-        }
-        // ---- (5) nearest hit for every lane still active
-        if (active) {
-            V3 res;
-            bool done = false;
-            if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
-                res = mk(0.0f, 0.0f, 0.0f);
-                done = true;
-            } else {
-                if (COUNT) cn.c[CN_H_BOUNCE]++;
-                load_material(c, h.mat, type, extra, col);
-                if (type == RT_LIGHT) {
-                    res = vmin(out, col);
-                    done = true;
-                } else if (type == RT_TEXTURED) {
-                    if (COUNT) cn.c[CN_N_TEXFETCH]++;
-                    col = texture_rgb(c.sc, h.u, h.v, h.tex);
-                }
-            }
-            if (done) {
-                s_slot[3u * sidx] = res.x;
-                s_slot[3u * sidx + 1u] = res.y;
-                s_slot[3u * sidx + 2u] = res.z;
-                atomicAdd(&s_ret[dq >> 8], 1u);
-                active = false;
-            }
-        }
-    }
-    flush_counters<COUNT>(cn, counters, 1);
-}
-
 // parity probe: one work-item per listed pixel-sample
 template <bool ACCEL>
 __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
@@ -1009,7 +775,7 @@ struct rt_context {
     uint32_t *d_live = nullptr;      // slots that need per-sample work + [capacity] = their count
     size_t slot_capacity = 0;
     bool prefix_sharing = true;
-    int sample_queue = 2;  // 0: fixed lanes (pt_samples), 1: one queue per wave (pt_samples_q), 2: ring of pixel slots (pt_samples_r)
+    bool sample_queue = true;
     uint32_t accum_count = 0;
     uint32_t sample_counter = 0;
     bool count_enabled = false;
@@ -1229,24 +995,10 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
     hipLaunchKernelGGL((pt_samples_q<C, A>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
 #define PT_CALL_FIXED(C, A) \
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
-        // ring: persistent waves, each streaming every n_waves-th live pixel through ppw slots
-        size_t lds_r = PT_LDS_STATIC_FLOAT4 * sizeof(float4) + 4 * (size_t)ring_wave_lds_bytes(ppw, count);
-#define PT_CALL_RING(C, A)                                                                                            \
-    do {                                                                                                              \
-        int per_cu = 0;                                                                                               \
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_samples_r<C, A>, 256, lds_r));          \
-        uint32_t resident = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)ctx->cu_count;                            \
-        uint32_t wanted = (n + 4 * ppw - 1) / (4 * ppw);                                                              \
-        dim3 gridr(wanted < resident ? wanted : resident);                                                            \
-        hipLaunchKernelGGL((pt_samples_r<C, A>), gridr, block, lds_r, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live,  \
-                           live_count, ctx->d_accum, ctx->d_counters, ppw);                                           \
-    } while (0)
         bool accel_on = scene_has_accel(sc);
         PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
-        if (queue && ctx->sample_queue >= 2 && !PT_STAMPS && !PT_LDS_SPHERES) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_RING);
-        else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
+        if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
-#undef PT_CALL_RING
 #undef PT_CALL_PREFIX
 #undef PT_CALL_QUEUE
 #undef PT_CALL_FIXED
@@ -1956,7 +1708,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     if (!ctx) return RT_EINVAL;
     switch (option) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
-        case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value > 2 ? 2 : (int)value; return RT_OK;
+        case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
         case RT_OPT_ACCEL:
             if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_ACCEL takes 0, 1 or 2");
             ctx->accel = value;

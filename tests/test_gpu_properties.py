@@ -161,7 +161,7 @@ def test_prefix_sharing_and_sample_queue_change_no_bit(name, kw, spps):
     t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
     for spp in spps:
         out = []
-        for share, queue in ((1, 2), (1, 1), (1, 0), (0, 0)):
+        for share, queue in ((1, 1), (1, 0), (0, 0)):
             t.setOption(t.OPT_PREFIX_SHARING, share)
             t.setOption(t.OPT_SAMPLE_QUEUE, queue)
             t.enableCounters(True)
