@@ -262,6 +262,9 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
     uint32_t b = pixels_per_wave * 5u * 16u + pixels_per_wave * 2u * 4u + pixels_per_wave * count * 3u * 4u;
     return (b + 15u) & ~15u;
 }
+#ifndef PT_UNIFORM_WAVE
+#define PT_UNIFORM_WAVE 1
+#endif
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 5  // waves per SIMD the register allocator must leave room for (A/B: 4 → 3.15 ms, 5 → 2.91, 6 → 3.39)
 #endif
@@ -282,7 +285,12 @@ __global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, 
     c.lsph = stage_spheres(sc, s_dyn + PT_LDS_STATIC_FLOAT4);
 #endif
 
+#if PT_UNIFORM_WAVE
+    // the wave index is wave-uniform, which the compiler cannot see: this puts everything derived from it in SGPRs
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+#else
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#endif
     char *wave_lds = reinterpret_cast<char *>(s_dyn + PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
