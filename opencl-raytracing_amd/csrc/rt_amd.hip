@@ -265,25 +265,31 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 6  // waves per SIMD the register allocator must leave room for: 6 = 80 VGPRs (A/B on C2: 5 → 2.62 ms, 6 → 2.48)
 #endif
-// Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES workgroups resident (6: 160 KB / 6 per
+#ifndef PT_Q_WAVES_ACCEL
+#define PT_Q_WAVES_ACCEL 6  // the BVH instantiations (A/B, 6 / 7 / 8: C5 at 16 spp 153 / 148 / 151 ms, C4 at 8 spp 97.5 / 103 / 109 ms)
+#endif
+#ifndef QUEUE_MIN_SAMPLES
+#define QUEUE_MIN_SAMPLES 384u
+#endif
+// Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES(_ACCEL) workgroups resident (6: 160 KB / 6 per
 // workgroup); when that leaves a wave fewer than 384 samples (256 spp and up: the queue's tail grows) the
 // budget of 5 resident workgroups is used instead — the kernel's 80 VGPRs fit either way.
-__host__ inline uint32_t queue_pixels_per_wave(uint32_t count) {
+__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, bool accel) {
     auto fit = [&](uint32_t workgroups) {
         uint32_t per_wave = (163840u / workgroups - (uint32_t)(PT_LDS_STATIC_FLOAT4 * sizeof(float4))) / 4u;
         uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
     };
-    uint32_t p = fit(PT_Q_WAVES);
-    if (p * count < 384u) {
+    uint32_t p = fit(accel ? PT_Q_WAVES_ACCEL : PT_Q_WAVES);
+    if (p * count < QUEUE_MIN_SAMPLES) {
         uint32_t p5 = fit(5u);
         if (p5 > p) p = p5;
     }
     return p < 1u ? 1u : p;
 }
 template <bool COUNT, bool ACCEL>
-__global__ __launch_bounds__(256, PT_Q_WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+__global__ __launch_bounds__(256, ACCEL ? PT_Q_WAVES_ACCEL : PT_Q_WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, unsigned long long *counters,
@@ -1005,7 +1011,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         HIP_TRY(ctx, hipMemsetAsync(live_count, 0, sizeof(uint32_t), ctx->stream));
         dim3 block(256), grid1((n + 255) / 256), grid2((unsigned)((((uint64_t)n << glog2) + 255) / 256));
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
-        uint32_t ppw = queue_pixels_per_wave(count);
+        uint32_t ppw = queue_pixels_per_wave(count, scene_has_accel(sc));
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
         size_t lds_q = (PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) * sizeof(float4) +
