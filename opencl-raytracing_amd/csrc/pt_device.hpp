@@ -34,6 +34,7 @@ struct V3 {
 };
 
 #define PT_DEV __device__ __forceinline__
+#define PT_HD __host__ __device__ inline
 
 PT_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
 PT_DEV V3 ld3(const rt_float3 &f) { return V3{f.x, f.y, f.z}; }
@@ -172,10 +173,19 @@ PT_DEV float schlick_r0(float ratio) {
 }
 
 // ---- materials in LDS ----------------------------------------------------------
+// Compact layout, sized by the scene: materials [0, 2M), sphere winner records [2M, 2M + 2S), plane
+// records after them; a set that exceeds its cap is not staged (0 entries, read from global memory).
+// pt_samples_q sizes its dynamic LDS by lds_static_used(), the other kernels hold the maximum statically.
+PT_HD uint32_t lds_mat_n(uint32_t material_count) { return material_count <= PT_LDS_MATERIALS ? 2u * material_count : 0u; }
+PT_HD uint32_t lds_win_n(uint32_t sphere_count) { return sphere_count <= PT_LDS_WINNERS ? 2u * sphere_count : 0u; }
+PT_HD uint32_t lds_pln_n(uint32_t plane_count) { return plane_count <= PT_LDS_PLANES ? plane_count : 0u; }
+PT_HD uint32_t lds_static_used(uint32_t material_count, uint32_t sphere_count, uint32_t plane_count) {
+    return lds_mat_n(material_count) + lds_win_n(sphere_count) + lds_pln_n(plane_count);  // float4 units
+}
 // call at kernel start by every thread of the workgroup (contains a barrier)
 PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
-    bool mats = sc.material_count <= PT_LDS_MATERIALS;
-    if (mats)
+    const uint32_t nm = lds_mat_n(sc.material_count), nw = lds_win_n(sc.sphere_count), np = lds_pln_n(sc.plane_count);
+    if (nm)
         for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
             const rt_material &m = sc.materials[i];
             lds[2 * i] = make_float4(m.color.x, m.color.y, m.color.z, m.extra_data);
@@ -186,27 +196,26 @@ PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
             lds[2 * i + 1] = make_float4(__int_as_float(m.type), inv, schlick_r0(m.extra_data), schlick_r0(inv));
         }
     // winner records of small sphere sets, after the materials: [2i] = (pos.xyz, r), [2i+1].x = mat_ID bits
-    if (sc.sphere_count <= PT_LDS_WINNERS)
+    if (nw)
         for (uint32_t i = threadIdx.x; i < sc.sphere_count; i += blockDim.x) {
             const rt_sphere &s = sc.spheres[i];
-            lds[2 * PT_LDS_MATERIALS + 2 * i] = make_float4(s.pos.x, s.pos.y, s.pos.z, s.r);
-            lds[2 * PT_LDS_MATERIALS + 2 * i + 1] = make_float4(__uint_as_float(s.mat_ID), 0.0f, 0.0f, 0.0f);
+            lds[nm + 2 * i] = make_float4(s.pos.x, s.pos.y, s.pos.z, s.r);
+            lds[nm + 2 * i + 1] = make_float4(__uint_as_float(s.mat_ID), 0.0f, 0.0f, 0.0f);
         }
     // plane winner records: (normal.xyz, mat_ID bits)
-    if (sc.plane_count <= PT_LDS_PLANES)
+    if (np)
         for (uint32_t i = threadIdx.x; i < sc.plane_count; i += blockDim.x) {
             const rt_plane &p = sc.planes[i];
-            lds[2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS + i] =
-                make_float4(p.normal.x, p.normal.y, p.normal.z, __uint_as_float(p.mat_ID));
+            lds[nm + nw + i] = make_float4(p.normal.x, p.normal.y, p.normal.z, __uint_as_float(p.mat_ID));
         }
     __syncthreads();
-    return mats ? lds : nullptr;
+    return nm ? lds : nullptr;
 }
 PT_DEV const float4 *staged_winners(const DeviceScene &sc, const float4 *lds) {
-    return sc.sphere_count <= PT_LDS_WINNERS ? lds + 2 * PT_LDS_MATERIALS : nullptr;
+    return lds_win_n(sc.sphere_count) ? lds + lds_mat_n(sc.material_count) : nullptr;
 }
 PT_DEV const float4 *staged_planes(const DeviceScene &sc, const float4 *lds) {
-    return sc.plane_count <= PT_LDS_PLANES ? lds + 2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS : nullptr;
+    return lds_pln_n(sc.plane_count) ? lds + lds_mat_n(sc.material_count) + lds_win_n(sc.sphere_count) : nullptr;
 }
 // PT_LDS_SPHERES experiment: stage the sphere test data of small scenes (after stage_materials' barrier
 // has been passed by every thread; contains its own barrier)

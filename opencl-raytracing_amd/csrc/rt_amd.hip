@@ -274,9 +274,9 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 // Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES(_ACCEL) workgroups resident (6: 160 KB / 6 per
 // workgroup); when that leaves a wave fewer than 384 samples (256 spp and up: the queue's tail grows) the
 // budget of 5 resident workgroups is used instead — the kernel's 80 VGPRs fit either way.
-__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, bool accel) {
+__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, bool accel, uint32_t static_float4) {
     auto fit = [&](uint32_t workgroups) {
-        uint32_t per_wave = (163840u / workgroups - (uint32_t)(PT_LDS_STATIC_FLOAT4 * sizeof(float4))) / 4u;
+        uint32_t per_wave = (163840u / workgroups - static_float4 * (uint32_t)sizeof(float4)) / 4u - 15u;
         uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, ACCEL ? PT_Q_WAVES_ACCEL : PT_Q_WAVES) void pt
     c.lwin = staged_winners(sc, s_mat);
     c.lpln = staged_planes(sc, s_mat);
 #if PT_LDS_SPHERES
-    c.lsph = stage_spheres(sc, s_dyn + PT_LDS_STATIC_FLOAT4);
+    c.lsph = stage_spheres(sc, s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count));
 #endif
 
 #if PT_UNIFORM_WAVE
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256, ACCEL ? PT_Q_WAVES_ACCEL : PT_Q_WAVES) void pt
 #else
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 #endif
-    char *wave_lds = reinterpret_cast<char *>(s_dyn + PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
+    char *wave_lds = reinterpret_cast<char *>(s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
+                                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
@@ -1011,11 +1012,12 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         HIP_TRY(ctx, hipMemsetAsync(live_count, 0, sizeof(uint32_t), ctx->stream));
         dim3 block(256), grid1((n + 255) / 256), grid2((unsigned)((((uint64_t)n << glog2) + 255) / 256));
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
-        uint32_t ppw = queue_pixels_per_wave(count, scene_has_accel(sc));
+        uint32_t static_f4 = lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
+                             (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
+        uint32_t ppw = queue_pixels_per_wave(count, scene_has_accel(sc), static_f4);
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
-        size_t lds_q = (PT_LDS_STATIC_FLOAT4 + (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) * sizeof(float4) +
-                       4 * (size_t)queue_wave_lds_bytes(ppw, count);
+        size_t lds_q = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
 #define PT_CALL_QUEUE(C, A) \
