@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 1   // idle lanes that trigger a refill
 #endif
+#ifndef QUEUE_MAX_PIXELS
 #define QUEUE_MAX_PIXELS 16
+#endif
 // dynamic LDS of pt_samples_q, per workgroup: materials, then per wave {records, coordinates, slots}
 __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wave, uint32_t count) {
     uint32_t b = pixels_per_wave * 5u * 16u + pixels_per_wave * 2u * 4u + pixels_per_wave * count * 3u * 4u;
