@@ -492,3 +492,20 @@ def test_mesh_bvh_keeps_faces_accepted_far_from_the_ray(edge, oracle):
         found += out[0][1]["h_tri"] > 0
     assert found >= len(pick) // 2
     t.close()
+
+
+def test_sample_queue_over_many_sample_counts():
+    """Pixels per wave, lanes per pixel and the LDS layout all depend on the sample count: the queue path
+    against the fixed-lane path for counts around every boundary (powers of two ± 1, the 512-sample cap)."""
+    wl = rt.workloads.get("all_kinds", width=96, height=56)
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    for spp in (2, 5, 7, 31, 33, 48, 63, 65, 96, 200, 255, 257, 384, 511, 512):
+        out = []
+        for queue in (1, 0):
+            t.setOption(t.OPT_SAMPLE_QUEUE, queue)
+            t.clear()
+            t.renderSamples(wl.camera, 3, spp)
+            out.append(t.readLinear())
+        assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32)), spp
+        assert (out[0][..., :3].sum(-1) > 0).mean() > 0.15
+    t.close()
