@@ -584,6 +584,9 @@ void make_table(uint64_t seed, float *out) {
 // centroids; median split when no bin boundary separates them), leaves of <= 4 spheres; children
 // are allocated in adjacent pairs (left at an odd index, lower coordinates along the split axis),
 // every node records its parent and split axis for the stackless ordered traversal.
+#ifndef SPHERE_BVH_LEAF
+#define SPHERE_BVH_LEAF 4  // spheres per leaf (<= 7)
+#endif
 struct BvhBuild {
     const rt_sphere *sph;
     std::vector<uint32_t> order;
@@ -607,7 +610,7 @@ struct BvhBuild {
         float lo[3], hi[3];
         bounds(b, e, lo, hi);
         uint32_t A = parent, B;
-        if (e - b <= 4) {
+        if (e - b <= SPHERE_BVH_LEAF) {
             uint32_t first = (uint32_t)leaf_sph.size();
             for (uint32_t i = b; i < e; i++) {
                 const rt_sphere &s = sph[order[i]];
