@@ -268,7 +268,10 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #define PT_Q_WAVES 6  // waves per SIMD the register allocator must leave room for: 6 = 80 VGPRs (A/B on C2: 5 → 2.62 ms, 6 → 2.48)
 #endif
 #ifndef PT_Q_WAVES_ACCEL
-#define PT_Q_WAVES_ACCEL 6  // the BVH instantiations (A/B, 6 / 7 / 8: C5 at 16 spp 153 / 148 / 151 ms, C4 at 8 spp 97.5 / 103 / 109 ms)
+#define PT_Q_WAVES_ACCEL 6  // scenes with a mesh BVH (A/B, 5 / 6 / 7 / 8: C5 at 16 spp 165 / 153 / 148 / 151 ms)
+#endif
+#ifndef PT_Q_WAVES_SPHERE_BVH
+#define PT_Q_WAVES_SPHERE_BVH 5  // scenes whose only BVH is the sphere BVH (C4 at 64 spp: 5 → 772 ms, 6 → 794 ms)
 #endif
 #ifndef QUEUE_MIN_SAMPLES
 #define QUEUE_MIN_SAMPLES 384u
@@ -276,22 +279,22 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 // Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES(_ACCEL) workgroups resident (6: 160 KB / 6 per
 // workgroup); when that leaves a wave fewer than 384 samples (256 spp and up: the queue's tail grows) the
 // budget of 5 resident workgroups is used instead — the kernel's 80 VGPRs fit either way.
-__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, bool accel, uint32_t static_float4) {
+__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, uint32_t static_float4) {
     auto fit = [&](uint32_t workgroups) {
         uint32_t per_wave = (163840u / workgroups - static_float4 * (uint32_t)sizeof(float4)) / 4u - 15u;
         uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
     };
-    uint32_t p = fit(accel ? PT_Q_WAVES_ACCEL : PT_Q_WAVES);
+    uint32_t p = fit(waves);
     if (p * count < QUEUE_MIN_SAMPLES) {
         uint32_t p5 = fit(5u);
         if (p5 > p) p = p5;
     }
     return p < 1u ? 1u : p;
 }
-template <bool COUNT, bool ACCEL>
-__global__ __launch_bounds__(256, ACCEL ? PT_Q_WAVES_ACCEL : PT_Q_WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+template <bool COUNT, bool ACCEL, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, unsigned long long *counters,
@@ -1019,14 +1022,22 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
         uint32_t static_f4 = lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
-        uint32_t ppw = queue_pixels_per_wave(count, scene_has_accel(sc), static_f4);
+        const bool sphere_bvh_only = sc.bvh_node_count != 0 && sc.mesh_bvh_root == nullptr;
+        const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
+        uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4);
         dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
         size_t lds_q = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
-#define PT_CALL_QUEUE(C, A) \
-    hipLaunchKernelGGL((pt_samples_q<C, A>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+#define PT_CALL_QUEUE_W(C, A, W) \
+    hipLaunchKernelGGL((pt_samples_q<C, A, W>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+#define PT_CALL_QUEUE(C, A)                                                            \
+    do {                                                                               \
+        if (!(A)) PT_CALL_QUEUE_W(C, false, PT_Q_WAVES);                               \
+        else if (sphere_bvh_only) PT_CALL_QUEUE_W(C, true, PT_Q_WAVES_SPHERE_BVH);     \
+        else PT_CALL_QUEUE_W(C, true, PT_Q_WAVES_ACCEL);                               \
+    } while (0)
 #define PT_CALL_FIXED(C, A) \
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
         bool accel_on = scene_has_accel(sc);
@@ -1035,6 +1046,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
 #undef PT_CALL_PREFIX
 #undef PT_CALL_QUEUE
+#undef PT_CALL_QUEUE_W
 #undef PT_CALL_FIXED
     }
     HIP_TRY(ctx, hipGetLastError());
