@@ -50,7 +50,7 @@ per_kernel = {}
 for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
-            if k in r["Kernel_Name"]:
+            if k.rstrip(">") in r["Kernel_Name"]:   # "pt_samples_q<false, true>" also matches "<false, true, 6>"
                 per_kernel.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 # one trace call = one launch of each listed kernel: sum their per-launch means
 counters = {}
