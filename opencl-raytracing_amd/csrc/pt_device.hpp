@@ -505,13 +505,19 @@ struct Hit {
 // primitive keeps a tie); inside a mesh the FIRST front-facing hit in face
 // order wins, not the nearest.
 // ACCEL = false compiles the BVH walks out (scenes without a BVH keep the lean kernel).
+// The nearest-hit search in three parts, so that a kernel can interleave the (long, divergent) mesh walks
+// of part 2 with other work: 1 spheres / planes / lenses, 2 models, 3 counters + winner's record.
+struct Nearest {
+    float t = RT_MAX_DISTANCE;
+    uint32_t id = PT_NO_HIT;
+    uint32_t face = 0, mat = 0;
+    float u = 0.0f, v = 0.0f;
+};
 template <bool COUNT, bool ACCEL>
-PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
+PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
     const DeviceScene &sc = c.sc;
-    float best_t = RT_MAX_DISTANCE;
-    uint32_t best_id = PT_NO_HIT;
-    uint32_t best_face = 0, best_mat = 0;
-    float best_u = 0.0f, best_v = 0.0f;
+    float best_t = nb.t;
+    uint32_t best_id = nb.id;
 
     // spheres: through the BVH when one was built, for lanes whose direction is (nearly) unit length
     bool brute = true;
@@ -626,6 +632,17 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
             best_id = K_LENS | i;
         }
     }
+    nb.t = best_t;
+    nb.id = best_id;
+}
+
+template <bool COUNT, bool ACCEL>
+PT_DEV void hit_models(const Ctx &c, const Ray &r, Nearest &nb) {
+    const DeviceScene &sc = c.sc;
+    float best_t = nb.t;
+    uint32_t best_id = nb.id;
+    uint32_t best_face = nb.face, best_mat = nb.mat;
+    float best_u = nb.u, best_v = nb.v;
     for (uint32_t mo = 0; mo < (PT_NO_MODELS ? 0u : sc.model_count); mo++) {
         const rt_model &model = sc.models[mo];
         float model_best = RT_MAX_DISTANCE;  // hitModel's own hit_min (:307)
@@ -694,6 +711,20 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         }
     }
 
+    nb.t = best_t;
+    nb.id = best_id;
+    nb.face = best_face;
+    nb.mat = best_mat;
+    nb.u = best_u;
+    nb.v = best_v;
+}
+
+template <bool COUNT>
+PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) {
+    const DeviceScene &sc = c.sc;
+    const float best_t = nb.t;
+    const uint32_t best_id = nb.id, best_face = nb.face, best_mat = nb.mat;
+    const float best_u = nb.u, best_v = nb.v;
     if (COUNT) {
         c.cn->c[CN_BOUNCES]++;
         c.cn->c[CN_T_SPHERE] += sc.sphere_count;
@@ -760,6 +791,16 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
         hit.n = (hit.p - centre) / rad;
     }
     return true;
+}
+
+
+// :322-360
+template <bool COUNT, bool ACCEL>
+PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
+    Nearest nb;
+    hit_primitives<COUNT, ACCEL>(c, r, nb);
+    hit_models<COUNT, ACCEL>(c, r, nb);
+    return hit_finish<COUNT>(c, r, nb, hit);
 }
 
 // ---- materials -------------------------------------------------------------------

@@ -65,28 +65,30 @@
 // MODE 1: count  — number of faces with index < best_face whose hitTriangle succeeds (any
 //                  facing): the reference's H_tri counter needs the back-facing hits it
 //                  stepped over before its first front-facing one.
+// The walk is stackless, so (cur, state) is its whole position: mesh_bvh_steps advances it by at most
+// max_steps node visits and returns true once the tree is exhausted — a kernel can interleave walks of
+// different lengths with other work (pt_samples_w).  Start with cur = root, state = 0.
 template <int MODE>
-PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
-                              float &fu, float &fv, LaneCounters *dbg = nullptr) {
+PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &cur, int &state,
+                           uint32_t &best_face, float &ft, float &fu, float &fv, uint32_t max_steps, uint32_t &hits,
+                           LaneCounters *dbg = nullptr) {
     float dlen = sqrtf(dot(r.d, r.d));
     float inv_len = 1.0f / dlen;
     V3 dh = r.d * inv_len;
     V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
     uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
-    uint32_t hits = 0;
 
     enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
-    uint32_t cur = root;
-    int state = FROM_PARENT;
-    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; guard++) {  // every node is entered at most 3 times
+    bool finished = false;
+    for (uint32_t guard = 0; guard < max_steps; guard++) {  // every node is entered at most 3 times
         const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
         float4 a = nd[0], b = nd[1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
         uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
         if (state == FROM_CHILD) {
-            if (cur == root) break;
+            if (cur == root) { finished = true; break; }
             const float4 *pn = sc.mbvh_nodes + 4 * (size_t)parent;
             uint32_t pleft = __float_as_uint(pn[1].w), paxis = (__float_as_uint(pn[0].w) >> 28) & 3u;
             uint32_t pnear = pleft + ((far_first >> paxis) & 1u);
@@ -182,6 +184,7 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
             cur = B + ((far_first >> axis) & 1u);
             state = FROM_PARENT;
         } else if (cur == root) {
+            finished = true;
             break;
         } else if (state == FROM_PARENT) {
             cur = sibling;
@@ -191,5 +194,14 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
             state = FROM_CHILD;
         }
     }
+    return finished;
+}
+
+template <int MODE>
+PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
+                              float &fu, float &fv, LaneCounters *dbg = nullptr) {
+    uint32_t cur = root, hits = 0;
+    int state = 0;
+    (void)mesh_bvh_steps<MODE>(sc, r, root, cur, state, best_face, ft, fu, fv, 0x7FFFFFFFu, hits, dbg);
     return hits;
 }

@@ -485,6 +485,204 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
     flush_counters<COUNT>(cn, counters, 1);
 }
 
+// pt_samples_w — the sample queue for scenes whose only model is ONE mesh with a BVH (C5).  The mesh walk
+// is the bulk of such a frame, and its length differs per lane from a handful of nodes (the root is missed)
+// to hundreds: run in place, a wave executes the walk loop until its slowest lane is through — rocprofv3
+// counted 9 of 64 lanes active per VALU instruction on C5.  Here every lane is a small state machine
+//     0 material interaction + spheres/planes/lenses → 1 walking → 2 winner's record, material, next bounce
+// and each loop iteration advances EVERY walking lane by at most PT_WALK_STEPS nodes (the stackless walk's
+// whole position is (node, state)), while lanes in the cheap states 0 and 2 pass through them: lanes start
+// and finish walks at different times, so the walk loop always has many lanes in it.  Same arithmetic per
+// sample as pt_samples_q, same slots, same summation order: bit-identical.
+#ifndef PT_WALK_STEPS
+#define PT_WALK_STEPS 24u  // A/B: 8 → 122.9 ms, 16 → 118.3, 24 → 116.5, 48 → 118.4
+#endif
+#ifndef PT_W_WAVES
+#define PT_W_WAVES 5  // A/B on C5 at 16 spp: 4 → 116.5 ms, 5 → 110.2, 6 → 116.1
+#endif
+__global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+                                                    const uint32_t *__restrict__ live,
+                                                    const uint32_t *__restrict__ live_count,
+                                                    float4 *__restrict__ accum, uint32_t pixels_per_wave) {
+    extern __shared__ float4 s_dyn[];
+    float4 *s_mat = s_dyn;
+    Ctx c{sc, stage_materials(sc, s_mat), nullptr};
+    c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    char *wave_lds = reinterpret_cast<char *>(s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count)) +
+                     (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
+    float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
+    uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
+    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
+    const uint32_t n_live = *live_count;
+    const uint32_t pix0 = (blockIdx.x * 4u + wave) * pixels_per_wave;
+    const uint32_t npix = pix0 < n_live ? min(pixels_per_wave, n_live - pix0) : 0u;
+    const uint32_t count = fp.count, total = npix * count;
+    const float4 *rec = s_rec;
+    const uint32_t *xy = s_xy;
+    for (uint32_t i = lane; i < npix * 5u; i += 64u) {
+        uint32_t p = i / 5u, part = i - p * 5u;
+        s_rec[i] = reinterpret_cast<const float4 *>(recs + pix0 + p)[part];
+    }
+    if (lane < npix) {
+        uint32_t x = 0, y = 0;
+        (void)slot_to_pixel(fp, live[pix0 + lane], x, y);
+        s_xy[2 * lane] = x;
+        s_xy[2 * lane + 1] = y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // the one model and its one mesh (wave-uniform)
+    const uint32_t mesh_i = sc.models[0].mesh_anchor;
+    const uint32_t model_mat = sc.models[0].mat_ID;
+    const uint32_t face_count = sc.meshes[mesh_i].face_count;
+    const uint32_t root = sc.mesh_bvh_root[mesh_i];
+
+    const float inv_count = 1.0f / (float)count;
+    uint32_t next = 0;  // wave-uniform head of the queue
+    bool active = false;
+    int phase = 0;
+    uint32_t idx = 0, depth = 0, sample = 0, gx = 0, gy = 0;
+    int type = 0;
+    float extra = 0.0f;
+    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);
+    Ray r;
+    r.o = r.d = mk(0.0f, 0.0f, 0.0f);
+    Hit h;
+    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.tex = h.mat = 0;
+    float nb_t = RT_MAX_DISTANCE;       // nearest sphere / plane / lens of the current bounce
+    uint32_t nb_id = PT_NO_HIT;
+    uint32_t wcur = 0, wbest = 0;       // the walk's position and its best face so far
+    int wstate = 0;
+    float wt = 0.0f, wu = 0.0f, wv = 0.0f;
+
+    // every iteration takes samples off the queue, or moves every active lane on (a bounce, or up to
+    // PT_WALK_STEPS nodes of a walk that visits each of the < 2^28 nodes at most 3 times)
+    for (unsigned long long guard = ((unsigned long long)total + 1ull) * (RT_DEPTH + 2ull) * (3ull * (1ull << 28) / PT_WALK_STEPS + 4ull); guard; guard--) {
+        // ---- refill idle lanes from the queue
+        bool need = !active;
+        unsigned long long m = __ballot(need);
+        if (m && next < total) {
+            uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (need && cand < total) {
+                idx = cand;
+                uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);  // = idx / count exactly (pt_samples_q)
+                sample = fp.first + (idx - p * count);
+                float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
+                       q4 = rec[5 * p + 4];
+                gx = xy[2 * p];
+                gy = xy[2 * p + 1];
+                uint32_t bits = __float_as_uint(q0.w);
+                if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
+                    slot[3 * idx] = q3.x;
+                    slot[3 * idx + 1] = q3.y;
+                    slot[3 * idx + 2] = q3.z;
+                } else {
+                    depth = (bits >> 8) & 0xFFu;
+                    type = (int)(bits >> 16);
+                    h.p = xyz(q0);
+                    h.n = xyz(q1);
+                    extra = q1.w;
+                    r.o = xyz(q0);
+                    r.d = xyz(q2);
+                    h.mat = __float_as_uint(q2.w);
+                    out = xyz(q3);
+                    col = xyz(q4);
+                    active = true;
+                    phase = 0;
+                }
+            }
+            next += (uint32_t)__popcll(m);
+        }
+        if (!__any(active)) {
+            if (next >= total) break;
+            continue;
+        }
+        // ---- state 0: one material interaction, then the primitives that are not models
+        if (active && phase == 0) {
+            Rnd rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+            scatter<false>(c, r, out, h, type, extra, col, rnd);
+            depth++;
+            if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
+                slot[3 * idx] = out.x;
+                slot[3 * idx + 1] = out.y;
+                slot[3 * idx + 2] = out.z;
+                active = false;
+            } else {
+                Nearest nb;
+                hit_primitives<false, true>(c, r, nb);
+                nb_t = nb.t;
+                nb_id = nb.id;
+                wcur = root;
+                wstate = 0;
+                wbest = face_count;
+                wt = wu = wv = 0.0f;
+                phase = 1;
+            }
+        }
+        // ---- state 1: a slice of the mesh walk
+        if (active && phase == 1) {
+            uint32_t hits = 0;
+            if (mesh_bvh_steps<0>(sc, r, root, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) phase = 2;
+        }
+        // ---- state 2: hitModel's bookkeeping for the one mesh (:305-320), the winner's record, its material
+        if (active && phase == 2) {
+            Nearest nb;
+            nb.t = nb_t;
+            nb.id = nb_id;
+            if (wbest < face_count && wt < RT_MAX_DISTANCE && wt < nb.t) {
+                nb.t = wt;
+                nb.id = K_MESH | mesh_i;
+                nb.face = wbest;
+                nb.mat = model_mat;
+                nb.u = wu;
+                nb.v = wv;
+            }
+            V3 res;
+            bool done = false;
+            if (!hit_finish<false>(c, r, nb, h)) {
+                res = mk(0.0f, 0.0f, 0.0f);
+                done = true;
+            } else {
+                load_material(c, h.mat, type, extra, col);
+                if (type == RT_LIGHT) {
+                    res = vmin(out, col);
+                    done = true;
+                } else if (type == RT_TEXTURED) {
+                    col = texture_rgb(c.sc, h.u, h.v, h.tex);
+                }
+            }
+            phase = 0;
+            if (done) {
+                slot[3 * idx] = res.x;
+                slot[3 * idx + 1] = res.y;
+                slot[3 * idx + 2] = res.z;
+                active = false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- per-pixel sums in pt_render's order
+    const uint32_t g = 1u << fp.group_log2, ppp = 64u >> fp.group_log2;
+    for (uint32_t pb = 0; pb < npix; pb += ppp) {
+        uint32_t p = pb + (lane >> fp.group_log2), l = lane & (g - 1u);
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        if (p < npix)
+            for (uint32_t j = l; j < count; j += g) {
+                const float *sl = slot + 3u * (p * count + j);
+                sum = sum + mk(sl[0], sl[1], sl[2]);
+            }
+        sum = group_sum(sum, g);
+        if (p < npix && l == 0) accumulate(accum, (size_t)xy[2 * p + 1] * fp.w + xy[2 * p], sum, count);
+    }
+}
+
 // parity probe: one work-item per listed pixel-sample
 template <bool ACCEL>
 __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, const uint32_t *__restrict__ xs,
@@ -813,6 +1011,8 @@ struct rt_context {
     size_t slot_capacity = 0;
     bool prefix_sharing = true;
     bool sample_queue = true;
+    bool single_mesh_model = false;  // the scene's models are ONE model of ONE mesh that has a BVH (pt_samples_w)
+    bool walk_slices = true;         // RT_OPT_WALK_SLICES
     uint32_t accum_count = 0;
     uint32_t sample_counter = 0;
     bool count_enabled = false;
@@ -1042,7 +1242,13 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
         bool accel_on = scene_has_accel(sc);
         PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
-        if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
+        if (queue && sc.mesh_bvh_root && ctx->single_mesh_model && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
+            // one mesh: interleaved walk slices (pt_samples_w), sized for its own occupancy target
+            uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4);
+            size_t lds_w = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw_w, count);
+            hipLaunchKernelGGL(pt_samples_w, dim3((n + 4 * ppw_w - 1) / (4 * ppw_w)), block, lds_w, ctx->stream, sc, fp, ctx->d_recs,
+                               ctx->d_live, live_count, ctx->d_accum, ppw_w);
+        } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
 #undef PT_CALL_PREFIX
 #undef PT_CALL_QUEUE
@@ -1174,6 +1380,7 @@ int rt_set_stream(rt_context *ctx, void *hip_stream) {
 int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
     if (!ctx) return RT_EINVAL;
     if (!d) return fail(ctx, RT_EINVAL, "scene is NULL");
+    ctx->single_mesh_model = false;
     struct { const void *p; uint32_t n; const char *name; } arrs[] = {
         {d->materials, d->material_count, "materials"}, {d->spheres, d->sphere_count, "spheres"},
         {d->planes, d->plane_count, "planes"}, {d->lenses, d->lens_count, "lenses"},
@@ -1262,6 +1469,8 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         HIP_TRY(ctx, ctx->mbvh_faces.upload(lfaces.data(), lfaces.size()));
         HIP_TRY(ctx, ctx->mbvh_face_idx.upload(lidx.data(), lidx.size()));
         HIP_TRY(ctx, ctx->mesh_bvh_root.upload(roots.data(), d->mesh_count));
+        ctx->single_mesh_model = ctx->have_mesh_bvh && d->model_count == 1 && d->models[0].mesh_count == 1 &&
+                                 d->models[0].mesh_anchor < d->mesh_count && roots[d->models[0].mesh_anchor] != PT_MESH_BVH_NONE;
     }
     ctx->bvh_node_count = 0;
     if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {
@@ -1755,6 +1964,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     switch (option) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
         case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
+        case RT_OPT_WALK_SLICES: ctx->walk_slices = value != 0; return RT_OK;
         case RT_OPT_ACCEL:
             if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_ACCEL takes 0, 1 or 2");
             ctx->accel = value;

@@ -509,3 +509,46 @@ def test_sample_queue_over_many_sample_counts():
         assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32)), spp
         assert (out[0][..., :3].sum(-1) > 0).mean() > 0.15
     t.close()
+
+
+@pytest.mark.parametrize("inside,textured", [(False, False), (True, False), (False, True)])
+def test_walk_slices_change_no_bit(inside, textured, oracle, table):
+    """Scenes whose only model is one BVH mesh run pt_samples_w (every lane a state machine, the mesh walk
+    advanced in slices of 24 nodes): against the walks in place, against the face scan, and the probes
+    against the oracle."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.3)
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.8, 0.8, 0.8), 1)
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)
+    s.addMaterial(rt._abi.T_TEXTURED, (1, 1, 1), 1)
+    pos, uv, idx = rt.workloads.uv_sphere(64, 40, radius=2.5, centre=(0.0, 2.0, 0.0))
+    s.addMesh(pos, uv, idx, texture_ID=0)
+    s.addModel(1, 3 if textured else 0)
+    s.setTextures(rt.workloads.checker_texture(32, 4))
+    s.addSphere((1, -200, 0), 100, 2)
+    s.addSphere((-4.5, 3.5, 1.0), 1.5, 1)
+    s.addPlane((0, 5, 0), (0, 1, 0), 1)
+    cam = rt.Camera(60, 16 / 9, (0.2, 2.1, 0.3) if inside else (-7, 0, -7), 45.0, 8.0).transferData()
+    w, h = 160, 90
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    rng = np.random.RandomState(23)
+    xs, ys, ss = rng.randint(0, w, 400), rng.randint(0, h, 400), rng.randint(0, 500, 400)
+    out = []
+    for slices, accel in ((1, 1), (0, 1), (0, 0)):
+        t.setOption(t.OPT_WALK_SLICES, slices)
+        t.setOption(t.OPT_ACCEL, accel)
+        frames = []
+        for spp in (3, 16, 64, 200):
+            t.clear()
+            t.renderSamples(cam, 2, spp)
+            frames.append(t.readLinear())
+        out.append(frames)
+    for k in (1, 2):
+        for a, b in zip(out[0], out[k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+    exp, _ = oracle.samples(s, cam, table, w, h, xs, ys, ss)
+    t.setOption(t.OPT_WALK_SLICES, 1)
+    t.setOption(t.OPT_ACCEL, 1)
+    assert np.array_equal(t.traceSamples(cam, xs, ys, ss).view(np.uint32), exp.view(np.uint32))
+    assert (out[0][2][..., :3].sum(-1) > 0).mean() > 0.2
+    t.close()
