@@ -283,6 +283,9 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float dis = b * b - cc;
     return sphere_root(b, cc, dis);
 }
+#ifndef PT_SPHERE_LEAF_EVERY
+#define PT_SPHERE_LEAF_EVERY 4u  // node steps between leaf phases of the sphere BVH walk (power of two)
+#endif
 #ifndef PT_SPHERE_ROUNDS
 #define PT_SPHERE_ROUNDS 0  // A/B: 1 = small scenes record a candidate mask first and take the square roots in per-lane rounds; no gain measured
 #endif
@@ -354,13 +357,19 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     uint32_t cur = 0;
     int state = FROM_PARENT;
     const uint32_t n_nodes = sc.bvh_node_count;
+    // "while-while": node steps for every lane that is not parked at a leaf; the sphere tests of the parked
+    // lanes only every PT_SPHERE_LEAF_EVERY steps, or when every lane is parked or through.  In place, the leaf
+    // block (up to four sphere tests with their square roots) ran on almost every step for one or two lanes.
+    bool finished = false, at_leaf = false;
+    uint32_t leaf_b = 0, leaf_parent = 0;
     for (uint32_t guard = 0; guard < 3u * n_nodes + 8u; guard++) {  // every node is entered at most 3 times
+      if (!finished && !at_leaf) do {
         float4 a = sc.bvh_nodes[2 * cur], b = sc.bvh_nodes[2 * cur + 1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
         uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
         if (state == FROM_CHILD) {
-            if (cur == 0) break;
+            if (cur == 0) { finished = true; break; }  // (leaves the do-block)
             // was `cur` the near child of its parent?  then its sibling (the far child) is next
             float4 pa = sc.bvh_nodes[2 * parent], pb = sc.bvh_nodes[2 * parent + 1];
             uint32_t pleft = __float_as_uint(pb.w), paxis = (__float_as_uint(pa.w) >> 28) & 3u;
@@ -371,7 +380,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
             } else {
                 cur = parent;
             }
-            continue;
+            break;  // (leaves the do-block: next step)
         }
         if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
         // entering `cur` from its parent or its sibling: slab test against the inflated box
@@ -391,24 +400,16 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                     || tmax < -1.0e-2f                               // box entirely behind the origin
                     || tmin > best_t * 1.00001f + 1.0e-2f;           // box entirely beyond the best hit
         bool leaf = (B & 0x80000000u) != 0;
-        if (!miss && leaf) {
-            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
-                float t = sphere_t(r, sc.bvh_sph[first + k]);
-                uint32_t idx = sc.bvh_idx[first + k];
-                if (t > 0.0f && (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK)))) {
-                    best_t = t;
-                    best_id = K_SPHERE | idx;
-                }
-            }
-        }
-        if (!miss && !leaf) {  // descend to the near child
+        if (!miss && leaf) {  // park here: the spheres are tested in the leaf phase below
+            at_leaf = true;
+            leaf_b = B;
+            leaf_parent = parent;
+        } else if (!miss) {  // descend to the near child
             uint32_t axis = (A >> 28) & 3u;
             cur = B + ((far_first >> axis) & 1u);
             state = FROM_PARENT;
         } else if (cur == 0) {
-            break;  // the root is a leaf or was missed
+            finished = true;  // the root was missed
         } else if (state == FROM_PARENT) {
             cur = sibling;
             state = FROM_SIBLING;
@@ -416,6 +417,34 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
             cur = parent;
             state = FROM_CHILD;
         }
+      } while (false);
+        // ---- leaf phase (wave-uniform decision)
+        bool flush = (guard & (PT_SPHERE_LEAF_EVERY - 1u)) == PT_SPHERE_LEAF_EVERY - 1u || __all(at_leaf || finished);
+        if (flush && __any(at_leaf)) {
+            if (at_leaf) {
+                uint32_t first = leaf_b & 0x0FFFFFFFu, cnt = (leaf_b >> 28) & 7u;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
+                    float t = sphere_t(r, sc.bvh_sph[first + k]);
+                    uint32_t idx = sc.bvh_idx[first + k];
+                    if (t > 0.0f && (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK)))) {
+                        best_t = t;
+                        best_id = K_SPHERE | idx;
+                    }
+                }
+                at_leaf = false;
+                if (cur == 0) {
+                    finished = true;  // the root is a leaf
+                } else if (state == FROM_PARENT) {
+                    cur = (cur & 1u) ? cur + 1u : cur - 1u;
+                    state = FROM_SIBLING;
+                } else {
+                    cur = leaf_parent;
+                    state = FROM_CHILD;
+                }
+            }
+        }
+        if (__all(finished)) break;
     }
 }
 
