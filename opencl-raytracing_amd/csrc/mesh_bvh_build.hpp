@@ -63,7 +63,7 @@ struct MeshBvhBuilder {
         }
     }
 
-    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e) {
+    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e, uint32_t parent_axis = 0) {
         float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         double ax[3] = {0, 0, 0};
@@ -102,7 +102,7 @@ struct MeshBvhBuilder {
         if (degenerate) q = 0.0f;
         if (!std::isfinite(emax)) { emax = INFINITY; q = 0.0f; }
 
-        uint32_t A = parent, B;
+        uint32_t A = parent | parent_axis << 30, B;  // the parent's split axis rides along (the walk's way back up)
         if (e - b <= MESH_BVH_LEAF) {
             uint32_t first = (uint32_t)(leaf_faces->size() / 3);
             for (uint32_t i = b; i < e; i++) {
@@ -176,8 +176,8 @@ struct MeshBvhBuilder {
             nodes->resize(nodes->size() + 8);
             A |= (uint32_t)axis << 28;
             B = left;
-            fill(left, me, b, mid);
-            fill(left + 1, me, mid, e);
+            fill(left, me, b, mid, (uint32_t)axis);
+            fill(left + 1, me, mid, e, (uint32_t)axis);
         }
         float4 *nd = nodes->data() + 4 * (size_t)me;
         nd[0] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);

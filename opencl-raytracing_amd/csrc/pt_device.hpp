@@ -363,25 +363,30 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     bool finished = false, at_leaf = false;
     uint32_t leaf_b = 0, leaf_parent = 0;
     for (uint32_t guard = 0; guard < 3u * n_nodes + 8u; guard++) {  // every node is entered at most 3 times
-      if (!finished && !at_leaf) do {
+      // the way back up costs no step of its own: a lane that has finished a subtree hops (up to twice) until
+      // it stands at a sibling that is still to be entered — (cur's own header word holds its parent, its
+      // parent's split axis, and children are adjacent with the left one odd, so no other node is read)
+      for (int hop = 0; hop < 2; hop++)
+        if (!finished && !at_leaf && state == FROM_CHILD) {
+            if (cur == 0) {
+                finished = true;
+            } else {
+                uint32_t hA = __float_as_uint(sc.bvh_nodes[2 * cur].w);
+                uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
+                uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
+                if (cur == pnear) {
+                    cur = (cur & 1u) ? cur + 1u : cur - 1u;
+                    state = FROM_SIBLING;
+                } else {
+                    cur = hA & 0x0FFFFFFFu;
+                }
+            }
+        }
+      if (!finished && !at_leaf && state != FROM_CHILD) do {
         float4 a = sc.bvh_nodes[2 * cur], b = sc.bvh_nodes[2 * cur + 1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
         uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
-        if (state == FROM_CHILD) {
-            if (cur == 0) { finished = true; break; }  // (leaves the do-block)
-            // was `cur` the near child of its parent?  then its sibling (the far child) is next
-            float4 pa = sc.bvh_nodes[2 * parent], pb = sc.bvh_nodes[2 * parent + 1];
-            uint32_t pleft = __float_as_uint(pb.w), paxis = (__float_as_uint(pa.w) >> 28) & 3u;
-            uint32_t pnear = pleft + ((far_first >> paxis) & 1u);
-            if (cur == pnear) {
-                cur = sibling;
-                state = FROM_SIBLING;
-            } else {
-                cur = parent;
-            }
-            break;  // (leaves the do-block: next step)
-        }
         if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
         // entering `cur` from its parent or its sibling: slab test against the inflated box
         // (fminf/fmaxf drop the NaN of 0·inf)

@@ -807,10 +807,10 @@ struct BvhBuild {
             }
         }
     }
-    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e) {
+    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e, uint32_t parent_axis = 0) {
         float lo[3], hi[3];
         bounds(b, e, lo, hi);
-        uint32_t A = parent, B;
+        uint32_t A = parent | parent_axis << 30, B;  // the parent's split axis rides along: the walk's way back up needs no parent load
         if (e - b <= SPHERE_BVH_LEAF) {
             uint32_t first = (uint32_t)leaf_sph.size();
             for (uint32_t i = b; i < e; i++) {
@@ -894,8 +894,8 @@ struct BvhBuild {
             nodes.resize(nodes.size() + 4);
             A |= (uint32_t)ax << 28;
             B = left;
-            fill(left, me, b, mid);
-            fill(left + 1, me, mid, e);
+            fill(left, me, b, mid, (uint32_t)ax);
+            fill(left + 1, me, mid, e, (uint32_t)ax);
         }
         nodes[2 * me] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         nodes[2 * me + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
