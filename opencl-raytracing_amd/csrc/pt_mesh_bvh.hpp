@@ -57,6 +57,9 @@
 #ifndef PT_MESH_SLAB_SCALE
 #define PT_MESH_SLAB_SCALE 1.0f  // test hook: < 1 must break tests/test_gpu_properties.py::test_mesh_bvh_grazing_rays
 #endif
+#ifndef PT_MESH_HOPS
+#define PT_MESH_HOPS 2
+#endif
 #ifndef PT_MESH_SLAB_SIN
 #define PT_MESH_SLAB_SIN 0.5f
 #endif
@@ -82,24 +85,32 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
     enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
     bool finished = false;
     for (uint32_t guard = 0; guard < max_steps; guard++) {  // every node is entered at most 3 times
+        // the way back up costs no step of its own: a lane that has finished a subtree hops (up to PT_MESH_HOPS
+        // times) until it stands at a sibling that is still to be entered.  cur's own header word holds its
+        // parent and its parent's split axis, and children are adjacent with the left one odd: no other node is read
+        for (int hop = 0; hop < PT_MESH_HOPS; hop++)
+            if (!finished && state == FROM_CHILD) {
+                if (cur == root) {
+                    finished = true;
+                } else {
+                    uint32_t hA = __float_as_uint(sc.mbvh_nodes[4 * (size_t)cur].w);
+                    uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
+                    uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
+                    if (cur == pnear) {
+                        cur = (cur & 1u) ? cur + 1u : cur - 1u;
+                        state = FROM_SIBLING;
+                    } else {
+                        cur = hA & 0x0FFFFFFFu;
+                    }
+                }
+            }
+        if (finished) break;
+        if (state == FROM_CHILD) continue;
         const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
         float4 a = nd[0], b = nd[1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
         uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
-        if (state == FROM_CHILD) {
-            if (cur == root) { finished = true; break; }
-            const float4 *pn = sc.mbvh_nodes + 4 * (size_t)parent;
-            uint32_t pleft = __float_as_uint(pn[1].w), paxis = (__float_as_uint(pn[0].w) >> 28) & 3u;
-            uint32_t pnear = pleft + ((far_first >> paxis) & 1u);
-            if (cur == pnear) {
-                cur = sibling;
-                state = FROM_SIBLING;
-            } else {
-                cur = parent;
-            }
-            continue;
-        }
         float4 cn = nd[2], ex = nd[3];
         if (dbg) dbg->c[CN_DBG_BVH_NODES]++;
         bool miss = __float_as_uint(ex.y) >= best_face;  // every face below has a larger index than the best
