@@ -283,6 +283,9 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float dis = b * b - cc;
     return sphere_root(b, cc, dis);
 }
+#ifndef PT_SPHERE_HOPS
+#define PT_SPHERE_HOPS 1  // A/B on C4 at 8 spp: 1 → 78.6 ms, 2 → 79.4, 3 → 82.9, 4 → 85.3 (and 95.4 with a hop per step)
+#endif
 #ifndef PT_SPHERE_LEAF_EVERY
 #define PT_SPHERE_LEAF_EVERY 4u  // node steps between leaf phases of the sphere BVH walk (power of two)
 #endif
@@ -366,7 +369,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
       // the way back up costs no step of its own: a lane that has finished a subtree hops (up to twice) until
       // it stands at a sibling that is still to be entered — (cur's own header word holds its parent, its
       // parent's split axis, and children are adjacent with the left one odd, so no other node is read)
-      for (int hop = 0; hop < 2; hop++)
+      for (int hop = 0; hop < PT_SPHERE_HOPS; hop++)
         if (!finished && !at_leaf && state == FROM_CHILD) {
             if (cur == 0) {
                 finished = true;

@@ -58,7 +58,7 @@
 #define PT_MESH_SLAB_SCALE 1.0f  // test hook: < 1 must break tests/test_gpu_properties.py::test_mesh_bvh_grazing_rays
 #endif
 #ifndef PT_MESH_HOPS
-#define PT_MESH_HOPS 2
+#define PT_MESH_HOPS 1  // A/B on C5 at 16 spp: 1 → 97.9 ms, 2 → 98.8, 3 → 107 (and 110.8 with a hop per step)
 #endif
 #ifndef PT_MESH_SLAB_SIN
 #define PT_MESH_SLAB_SIN 0.5f
