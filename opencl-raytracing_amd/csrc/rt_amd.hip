@@ -485,7 +485,8 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
     flush_counters<COUNT>(cn, counters, 1);
 }
 
-// pt_samples_w — the sample queue for scenes whose only model is ONE mesh with a BVH (C5).  The mesh walk
+// pt_samples_w — the sample queue for scenes in which every mesh of every model has a BVH (C5: one mesh of
+// 50 000 faces).  The mesh walk
 // is the bulk of such a frame, and its length differs per lane from a handful of nodes (the root is missed)
 // to hundreds: run in place, a wave executes the walk loop until its slowest lane is through — rocprofv3
 // counted 9 of 64 lanes active per VALU instruction on C5.  Here every lane is a small state machine
@@ -500,10 +501,12 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
 #ifndef PT_W_WAVES
 #define PT_W_WAVES 5  // A/B on C5 at 16 spp: 4 → 116.5 ms, 5 → 110.2, 6 → 116.1
 #endif
+template <bool MULTI>
 __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
-                                                    float4 *__restrict__ accum, uint32_t pixels_per_wave) {
+                                                    float4 *__restrict__ accum, uint32_t pixels_per_wave,
+                                                    const uint2 *__restrict__ jobs, uint32_t n_jobs) {
     extern __shared__ float4 s_dyn[];
     float4 *s_mat = s_dyn;
     Ctx c{sc, stage_materials(sc, s_mat), nullptr};
@@ -534,11 +537,13 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // the one model and its one mesh (wave-uniform)
-    const uint32_t mesh_i = sc.models[0].mesh_anchor;
-    const uint32_t model_mat = sc.models[0].mat_ID;
-    const uint32_t face_count = sc.meshes[mesh_i].face_count;
-    const uint32_t root = sc.mesh_bvh_root[mesh_i];
+    // The walks of a bounce, in the reference's order: jobs[j] = (mesh index, material of its model), model by
+    // model, mesh by mesh.  hitModel's "nearest of my meshes" followed by hitScene's "nearer than the best so
+    // far" (:305-320, :349-356) equals ONE running strict-< minimum over this flat list, which is what state 1
+    // keeps.  MULTI = false: a single job, its constants wave-uniform.
+    const uint32_t mesh0 = jobs[0].x, mat0 = jobs[0].y;
+    const uint32_t faces0 = sc.meshes[mesh0].face_count;
+    const uint32_t root0 = sc.mesh_bvh_root[mesh0];
 
     const float inv_count = 1.0f / (float)count;
     uint32_t next = 0;  // wave-uniform head of the queue
@@ -559,6 +564,9 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
     uint32_t wcur = 0, wbest = 0;       // the walk's position and its best face so far
     int wstate = 0;
     float wt = 0.0f, wu = 0.0f, wv = 0.0f;
+    uint32_t job = 0;                   // MULTI: the job being walked, and the winning mesh hit so far
+    uint32_t nb_face = 0, nb_mat = 0;
+    float nb_u = 0.0f, nb_v = 0.0f;
 
     // every iteration takes samples off the queue, or moves every active lane on (a bounce, or up to
     // PT_WALK_STEPS nodes of a walk that visits each of the < 2^28 nodes at most 3 times)
@@ -617,28 +625,69 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
                 hit_primitives<false, true>(c, r, nb);
                 nb_t = nb.t;
                 nb_id = nb.id;
-                wcur = root;
+                if (MULTI) {
+                    nb_face = nb_mat = 0;
+                    nb_u = nb_v = 0.0f;
+                }
+                wcur = root0;
                 wstate = 0;
-                wbest = face_count;
+                wbest = faces0;
                 wt = wu = wv = 0.0f;
+                job = 0;
                 phase = 1;
             }
         }
-        // ---- state 1: a slice of the mesh walk
+        // ---- state 1: a slice of the current job's mesh walk
         if (active && phase == 1) {
             uint32_t hits = 0;
-            if (mesh_bvh_steps<0>(sc, r, root, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) phase = 2;
+            uint32_t mesh_j = mesh0, mat_j = mat0, faces_j = faces0, root_j = root0;
+            if (MULTI) {
+                uint2 jb = jobs[job];
+                mesh_j = jb.x;
+                mat_j = jb.y;
+                faces_j = sc.meshes[mesh_j].face_count;
+                root_j = sc.mesh_bvh_root[mesh_j];
+            }
+            if (mesh_bvh_steps<0>(sc, r, root_j, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) {
+                if (!MULTI) {
+                    phase = 2;  // (the one job's result is merged in state 2, straight from the walk's registers)
+                } else {
+                if (wbest < faces_j && wt < RT_MAX_DISTANCE && wt < nb_t) {  // the running strict-< minimum
+                    nb_t = wt;
+                    nb_id = K_MESH | mesh_j;
+                    nb_face = wbest;
+                    nb_mat = mat_j;
+                    nb_u = wu;
+                    nb_v = wv;
+                }
+                job++;
+                if (MULTI && job < n_jobs) {  // next mesh: stay in state 1
+                    uint32_t mesh_n = jobs[job].x;
+                    wcur = sc.mesh_bvh_root[mesh_n];
+                    wstate = 0;
+                    wbest = sc.meshes[mesh_n].face_count;
+                    wt = wu = wv = 0.0f;
+                } else {
+                    phase = 2;
+                }
+                }
+            }
         }
-        // ---- state 2: hitModel's bookkeeping for the one mesh (:305-320), the winner's record, its material
+        // ---- state 2: the winner's record, its material
         if (active && phase == 2) {
             Nearest nb;
             nb.t = nb_t;
             nb.id = nb_id;
-            if (wbest < face_count && wt < RT_MAX_DISTANCE && wt < nb.t) {
+            if (MULTI) {
+                nb.face = nb_face;
+                nb.mat = nb_mat;
+                nb.u = nb_u;
+                nb.v = nb_v;
+            } else if (wbest < faces0 && wt < RT_MAX_DISTANCE && wt < nb.t) {
                 nb.t = wt;
-                nb.id = K_MESH | mesh_i;
+                nb.id = K_MESH | mesh0;
                 nb.face = wbest;
-                nb.mat = model_mat;
+                nb.mat = mat0;
                 nb.u = wu;
                 nb.v = wv;
             }
@@ -1011,7 +1060,8 @@ struct rt_context {
     size_t slot_capacity = 0;
     bool prefix_sharing = true;
     bool sample_queue = true;
-    bool single_mesh_model = false;  // the scene's models are ONE model of ONE mesh that has a BVH (pt_samples_w)
+    DevBuf<uint2> walk_jobs;         // (mesh, model material) of every model's meshes in hit order; empty unless
+                                     // every one of them has a BVH (pt_samples_w)
     bool walk_slices = true;         // RT_OPT_WALK_SLICES
     uint32_t accum_count = 0;
     uint32_t sample_counter = 0;
@@ -1242,12 +1292,17 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
         bool accel_on = scene_has_accel(sc);
         PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
-        if (queue && sc.mesh_bvh_root && ctx->single_mesh_model && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
-            // one mesh: interleaved walk slices (pt_samples_w), sized for its own occupancy target
+        if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
+            // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
             uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4);
             size_t lds_w = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw_w, count);
-            hipLaunchKernelGGL(pt_samples_w, dim3((n + 4 * ppw_w - 1) / (4 * ppw_w)), block, lds_w, ctx->stream, sc, fp, ctx->d_recs,
-                               ctx->d_live, live_count, ctx->d_accum, ppw_w);
+            dim3 gridw((n + 4 * ppw_w - 1) / (4 * ppw_w));
+            if (ctx->walk_jobs.n == 1)
+                hipLaunchKernelGGL(pt_samples_w<false>, gridw, block, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
+                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u);
+            else
+                hipLaunchKernelGGL(pt_samples_w<true>, gridw, block, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
+                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n);
         } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
 #undef PT_CALL_PREFIX
@@ -1348,6 +1403,7 @@ void rt_destroy(rt_context *ctx) {
     ctx->mbvh_nodes.release();
     ctx->mbvh_faces.release();
     ctx->mbvh_face_idx.release();
+    ctx->walk_jobs.release();
     ctx->mesh_bvh_root.release();
     ctx->bvh_nodes.release();
     ctx->bvh_sph.release();
@@ -1380,7 +1436,7 @@ int rt_set_stream(rt_context *ctx, void *hip_stream) {
 int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
     if (!ctx) return RT_EINVAL;
     if (!d) return fail(ctx, RT_EINVAL, "scene is NULL");
-    ctx->single_mesh_model = false;
+    ctx->walk_jobs.release();
     struct { const void *p; uint32_t n; const char *name; } arrs[] = {
         {d->materials, d->material_count, "materials"}, {d->spheres, d->sphere_count, "spheres"},
         {d->planes, d->plane_count, "planes"}, {d->lenses, d->lens_count, "lenses"},
@@ -1469,8 +1525,15 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         HIP_TRY(ctx, ctx->mbvh_faces.upload(lfaces.data(), lfaces.size()));
         HIP_TRY(ctx, ctx->mbvh_face_idx.upload(lidx.data(), lidx.size()));
         HIP_TRY(ctx, ctx->mesh_bvh_root.upload(roots.data(), d->mesh_count));
-        ctx->single_mesh_model = ctx->have_mesh_bvh && d->model_count == 1 && d->models[0].mesh_count == 1 &&
-                                 d->models[0].mesh_anchor < d->mesh_count && roots[d->models[0].mesh_anchor] != PT_MESH_BVH_NONE;
+        std::vector<uint2> jobs;
+        bool all_bvh = ctx->have_mesh_bvh && d->model_count > 0;
+        for (uint32_t mo = 0; mo < d->model_count && all_bvh; mo++)
+            for (uint32_t k = 0; k < d->models[mo].mesh_count && all_bvh; k++) {
+                uint32_t mi = d->models[mo].mesh_anchor + k;
+                all_bvh = mi < d->mesh_count && roots[mi] != PT_MESH_BVH_NONE;
+                jobs.push_back(make_uint2(mi, d->models[mo].mat_ID));
+            }
+        if (all_bvh && !jobs.empty() && jobs.size() < (1u << 16)) HIP_TRY(ctx, ctx->walk_jobs.upload(jobs.data(), jobs.size()));
     }
     ctx->bvh_node_count = 0;
     if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {

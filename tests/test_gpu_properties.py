@@ -552,3 +552,27 @@ def test_walk_slices_change_no_bit(inside, textured, oracle, table):
     assert np.array_equal(t.traceSamples(cam, xs, ys, ss).view(np.uint32), exp.view(np.uint32))
     assert (out[0][2][..., :3].sum(-1) > 0).mean() > 0.2
     t.close()
+
+
+@pytest.mark.parametrize("inside", [False, True])
+def test_walk_slices_with_several_meshes(inside):
+    """Two overlapping BVH meshes (dielectric and textured): the state machine walks them one after the
+    other per bounce (pt_samples_w<true>) — against the walks in place and against the face scan."""
+    s, cam = _mesh_scene(48, 30, inside)
+    w, h = 128, 72
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    out = []
+    for slices, accel in ((1, 1), (0, 1), (0, 0)):
+        t.setOption(t.OPT_WALK_SLICES, slices)
+        t.setOption(t.OPT_ACCEL, accel)
+        frames = []
+        for spp in (5, 64):
+            t.clear()
+            t.renderSamples(cam, 1, spp)
+            frames.append(t.readLinear())
+        out.append(frames)
+    for k in (1, 2):
+        for a, b in zip(out[0], out[k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+    assert (out[0][1][..., :3].sum(-1) > 0).mean() > 0.2
+    t.close()
