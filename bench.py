@@ -212,7 +212,7 @@ def main():
                        "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "pt_prefix + pt_samples_q (one fused trace call)", "kernel_ms": round(launch_ms, 4),
+                         "kernel": "pt_prefix + %s (one fused trace call)" % ("pt_samples_w" if args.workload == "c5" else "pt_samples_q"), "kernel_ms": round(launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_pixel_sample": round(alg_bytes / max(my_samples, 1), 1),
                          "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
