@@ -13,6 +13,8 @@
 #include <map>
 #include <sstream>
 
+#include <zlib.h>
+
 using rth::mat4;
 using rth::vec3;
 
@@ -214,7 +216,99 @@ std::vector<ObjMesh> read_obj(const std::string &path, std::map<std::string, std
     return meshes;
 }
 
-// binary PPM (P6, maxval 255) or PFM (PF, little endian) → RGBA32F, stb_image's ldr→hdr rule for 8-bit data
+// stb_image's 8-bit → float rule (stbi__ldr_to_hdr with the default l2h gamma 2.2f / scale 1.0f, which is what
+// stbi_loadf applies, src/scene.cpp:158): colour = (float)pow(byte / 255.0f, 2.2f) — a FLOAT quotient and the
+// float constant 2.2f, both promoted to double for pow() — and alpha = byte / 255.0f.  stb_image itself is not
+// in the reference tree (un-vendored), so this restates its published formula; parity with it is unpinned.
+struct LdrToHdr {
+    float colour[256], alpha[256];
+    LdrToHdr() {
+        for (int i = 0; i < 256; i++) {
+            float q = (float)i / 255.0f;
+            colour[i] = (float)std::pow((double)q, (double)2.2f);
+            alpha[i] = q;
+        }
+    }
+};
+const LdrToHdr &ldr_to_hdr() {
+    static const LdrToHdr t;
+    return t;
+}
+
+// PNG → 8-bit samples, `channels` per pixel.  Non-interlaced, 8 bits per sample, colour types 0 / 2 / 4 / 6
+// (grey, RGB, grey+alpha, RGBA) — what the reference's textures are (assets/textures/die.png: 1024², RGBA8).
+// zlib inflates the IDAT stream; the five scanline filters are undone here.  Returns "" or an error text.
+std::string read_png(const std::string &path, std::vector<unsigned char> &pix, int &w, int &h, int &channels) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "cannot open";
+    std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), sig, 8) != 0) return "not a PNG file";
+    auto be32 = [&](size_t at) {
+        return ((uint32_t)file[at] << 24) | ((uint32_t)file[at + 1] << 16) | ((uint32_t)file[at + 2] << 8) | (uint32_t)file[at + 3];
+    };
+    std::vector<unsigned char> idat;
+    bool have_ihdr = false;
+    int depth = 0, ctype = 0, interlace = 0;
+    for (size_t pos = 8; pos + 12 <= file.size();) {
+        uint32_t len = be32(pos);
+        if (pos + 12 + (size_t)len > file.size()) return "truncated chunk";
+        const unsigned char *type = &file[pos + 4], *data = &file[pos + 8];
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return "bad IHDR";
+            w = (int)be32(pos + 8);
+            h = (int)be32(pos + 12);
+            depth = data[8]; ctype = data[9]; interlace = data[12];
+            have_ihdr = true;
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    if (!have_ihdr || w < 1 || h < 1 || w > 32768 || h > 32768) return "bad header";
+    if (depth != 8 || interlace != 0) return "only 8-bit non-interlaced PNG is supported";
+    switch (ctype) {
+        case 0: channels = 1; break;
+        case 2: channels = 3; break;
+        case 4: channels = 2; break;
+        case 6: channels = 4; break;
+        default: return "palette PNG is not supported";
+    }
+    const size_t stride = (size_t)w * channels;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
+        return "inflate failed";
+    pix.assign(stride * (size_t)h, 0);
+    const int bpp = channels;
+    for (int y = 0; y < h; y++) {
+        const unsigned char *src = &raw[(stride + 1) * (size_t)y];
+        unsigned char *cur = &pix[stride * (size_t)y];
+        const unsigned char *up = y ? cur - stride : nullptr;
+        const int filter = src[0];
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
+            int pred;
+            switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: {
+                    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: return "bad scanline filter";
+            }
+            cur[x] = (unsigned char)(src[1 + x] + pred);
+        }
+    }
+    return "";
+}
+
+// binary PPM (P6, maxval 255) or PFM (PF, little endian) → RGBA32F (alpha 1): an EXTENSION for this build's own
+// synthetic assets — the reference only takes 4-channel images (src/scene.cpp:165-179)
 bool read_ppm_pfm(const std::string &path, std::vector<float> &rgba, int &w, int &h) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return false;
@@ -232,8 +326,7 @@ bool read_ppm_pfm(const std::string &path, std::vector<float> &rgba, int &w, int
         std::vector<unsigned char> buf((size_t)w * h * 3);
         in.read((char *)buf.data(), buf.size());
         if (!in) return false;
-        float lut[256];
-        for (int i = 0; i < 256; i++) lut[i] = (float)std::pow(i / 255.0, 2.2);
+        const float *lut = ldr_to_hdr().colour;
         rgba.resize((size_t)w * h * 4);
         for (size_t i = 0; i < (size_t)w * h; i++) {
             rgba[4 * i] = lut[buf[3 * i]];
@@ -312,6 +405,13 @@ void SceneCreator::loadModel(const std::string &path, cl_uint mat_ID, const mat4
     if (materials.size() <= mat_ID) fail("ERROR: MATERIAL OF ID: " + std::to_string(mat_ID) + " DOES NOT EXIST");
     std::map<std::string, std::string> mtl_tex;
     std::vector<ObjMesh> parts = read_obj(path, mtl_tex);
+    {
+        std::string d = dir_of(path);
+        if (d.empty()) d = ".";
+        bool seen = false;
+        for (const std::string &e : model_dirs) seen = seen || e == d;
+        if (!seen) model_dirs.push_back(d);
+    }
     bool textured = materials[mat_ID].type == t_textured;
     for (const ObjMesh &om : parts) {
         Mesh mesh;
@@ -352,6 +452,13 @@ void SceneCreator::setTextures(const float *rgba, int w, int h, int layers) {
     tex_layers = layers;
 }
 
+// Texture files.  The reference hands every map_Kd string to stbi_loadf as it is (src/scene.cpp:158); its own
+// .mtl files name an absolute path on the author's machine (assets/cube/cube.mtl:13), so a path that does not
+// exist is looked up again by its BASE NAME next to the models and the scene: <model dir>/../textures,
+// <model dir>, <scene dir>/../textures, ./assets/textures (the reference's tree seen from its working
+// directory), <base dir>/textures.  Relative paths are also tried against the base / model directories.
+// A PNG must be 4-channel, as in the reference (src/scene.cpp:165-179); PPM/PFM stand-ins (same stem) are an
+// extension for synthetic assets.
 void SceneCreator::loadTextures() {
     if (models.empty()) {
         tex_layers = 0;
@@ -360,21 +467,58 @@ void SceneCreator::loadTextures() {
     if (texture_paths.empty()) fail("ERROR: TEXTURE COUNT = 0");
     texture_data.clear();
     tex_layers = 0;
+    std::vector<std::string> dirs;
+    auto add_dir = [&](const std::string &d) {
+        for (const std::string &e : dirs) if (e == d) return;
+        dirs.push_back(d);
+    };
+    for (const std::string &d : model_dirs) { add_dir(join_path(d, "../textures")); add_dir(d); }
+    if (!scene_dir.empty()) add_dir(join_path(scene_dir, "../textures"));
+    add_dir("assets/textures");
+    if (!base_dir.empty()) { add_dir(join_path(base_dir, "textures")); add_dir(base_dir); }
     for (size_t id = 0; id < texture_paths.size(); id++) {
         const std::string &p = texture_paths[id];
-        std::string stem = p.substr(0, p.find_last_of('.'));
-        std::vector<std::string> candidates = {join_path(base_dir, p), join_path(base_dir, stem + ".ppm"),
-                                               join_path(base_dir, "textures/" + base_of(stem) + ".ppm"),
-                                               join_path(base_dir, stem + ".pfm")};
+        std::vector<std::string> candidates = {p};
+        if (!p.empty() && p[0] != '/') {
+            if (!base_dir.empty()) candidates.push_back(join_path(base_dir, p));
+            for (const std::string &d : model_dirs) candidates.push_back(join_path(d, p));
+        }
+        for (const std::string &d : dirs) candidates.push_back(join_path(d, base_of(p)));
+        const size_t n_as_named = candidates.size();
+        for (size_t k = 0; k < n_as_named; k++) {  // PPM / PFM stand-ins with the same stem
+            std::string stem = candidates[k].substr(0, candidates[k].find_last_of('.'));
+            candidates.push_back(stem + ".ppm");
+            candidates.push_back(stem + ".pfm");
+        }
         std::vector<float> img;
         int w = 0, h = 0;
         bool ok = false;
-        for (const std::string &c : candidates)
-            if (file_exists(c) && read_ppm_pfm(c, img, w, h)) { ok = true; break; }
-        if (!ok) fail("ERROR: STBimage: COULD NOT FIND THE TEXTURE (PPM/PFM only): " + p);
+        for (const std::string &c : candidates) {
+            if (!file_exists(c)) continue;
+            std::vector<unsigned char> pix;
+            int ch = 0;
+            std::string err = read_png(c, pix, w, h, ch);
+            if (err.empty()) {
+                if (ch != 4) fail("ERROR: STBimage: TEXTURE HAS A WRONG FORMAT: " + std::to_string(ch) + " INSTEAD OF 4 (RGBA)");
+                const LdrToHdr &t = ldr_to_hdr();
+                img.resize((size_t)w * h * 4);
+                for (size_t i = 0; i < (size_t)w * h; i++) {
+                    img[4 * i] = t.colour[pix[4 * i]];
+                    img[4 * i + 1] = t.colour[pix[4 * i + 1]];
+                    img[4 * i + 2] = t.colour[pix[4 * i + 2]];
+                    img[4 * i + 3] = t.alpha[pix[4 * i + 3]];
+                }
+                ok = true;
+                break;
+            }
+            if (err != "not a PNG file") fail("ERROR: STBimage: " + err + ": " + c);
+            if (read_ppm_pfm(c, img, w, h)) { ok = true; break; }
+        }
+        if (!ok) fail("ERROR: STBimage: COULD NOT FIND THE TEXTURE: " + p);
         if (id == 0) { tex_w = w; tex_h = h; }
         else if (w != tex_w || h != tex_h)
-            fail("ERROR: TEXTURES HAVE DIFFERENT SIZES: TEMPLATE: " + std::to_string(tex_w) + " x " + std::to_string(tex_h));
+            fail("ERROR: TEXTURES HAVE DIFFERENT SIZES: TEMPLATE: " + std::to_string(tex_w) + " x " + std::to_string(tex_h) +
+                 ", TEXTURE ID(" + std::to_string(id) + "): " + std::to_string(w) + " x " + std::to_string(h));
         texture_data.insert(texture_data.end(), img.begin(), img.end());
         tex_layers++;
     }
@@ -385,8 +529,19 @@ void SceneCreator::loadScene(const std::string &path) {
     if (!in) fail("ERROR: SCENE: NOT SUCCESFULLY READ: " + path);
     std::stringstream ss;
     ss << in.rdbuf();
-    if (base_dir.empty()) base_dir = dir_of(dir_of(path));  // assets/scenes/x.scene → assets/
+    scene_dir = dir_of(path);
+    if (base_dir.empty()) base_dir = dir_of(scene_dir);  // assets/scenes/x.scene → assets/
     loadSceneText(ss.str());
+}
+
+// `load:` paths are used AS WRITTEN, i.e. relative to the working directory, like the reference
+// (src/scene.cpp:355 → :195; assets/scenes/scene.scene:32 says "assets/cube/cube.obj").  Only when that file
+// does not exist is the path tried against the base directory and the scene's own directory.
+std::string SceneCreator::resolveModelPath(const std::string &p) const {
+    if (file_exists(p) || (!p.empty() && p[0] == '/')) return p;
+    if (!base_dir.empty() && file_exists(join_path(base_dir, p))) return join_path(base_dir, p);
+    if (!scene_dir.empty() && file_exists(join_path(scene_dir, p))) return join_path(scene_dir, p);
+    return p;
 }
 
 void SceneCreator::loadSceneText(const std::string &text) {
@@ -421,7 +576,7 @@ void SceneCreator::loadSceneText(const std::string &text) {
             } else if (word == "load") {
                 std::string p = f.getPath();
                 cl_uint mat = f.getUInt();
-                loadModel(join_path(base_dir, p), mat, model);
+                loadModel(resolveModelPath(p), mat, model);
                 model = mat4(1.0f);
             }
             continue;

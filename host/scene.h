@@ -6,8 +6,11 @@
 //   * loadModel is a minimal OBJ reader reproducing what Assimp yields for
 //     aiProcess_Triangulate | aiProcess_FlipUVs (src/scene.cpp:195): one vertex
 //     per face corner in file order, fan triangulation, v → 1 − v;
-//   * loadTextures reads binary PPM (P6) / PFM; a map_Kd naming another format is
-//     looked up with its extension replaced by .ppm (stb_image's RGB^2.2 applied).
+//   * loadTextures decodes 8-bit RGBA PNG (zlib inflate + the five scanline filters) with
+//     stb_image's published 8-bit → float rule, colour = (float)pow(byte/255.0f, 2.2f),
+//     alpha = byte/255.0f; a map_Kd path that does not exist (the reference's .mtl files
+//     name an absolute path on the author's machine) is looked up by base name next to
+//     the models / the scene; binary PPM (P6) / PFM with the same stem are an extension.
 // Errors throw SceneError (the reference prints and calls exit(-1), scene.cpp:29-32).
 #pragma once
 #include <stdexcept>
@@ -51,7 +54,9 @@ class SceneCreator {
     std::vector<float> texture_data;  // layers × h × w × RGBA32F
     int tex_w = 0, tex_h = 0, tex_layers = 0;
     cl_uint mesh_count_total = 0;
-    std::string base_dir;
+    std::string base_dir, scene_dir;
+    std::vector<std::string> model_dirs;  // directories of the OBJ files loaded so far (texture lookup)
+    std::string resolveModelPath(const std::string &p) const;
 
 public:
     void addMaterial(MatType type, const cl_float3 &color, cl_float extra_data);
@@ -63,7 +68,7 @@ public:
     void setTextures(const float *rgba, int w, int h, int layers);
     void loadScene(const std::string &path);
     void loadSceneText(const std::string &text);
-    void setBaseDir(const std::string &dir) { base_dir = dir; }  // where "load:" and map_Kd paths are resolved
+    void setBaseDir(const std::string &dir) { base_dir = dir; }  // fallback for "load:" / map_Kd paths that do not exist as written
 
     // what replaces setupBuffers/createScene/setKernelArgs (src/scene.cpp:46-108)
     rt_scene_desc describe();

@@ -47,9 +47,50 @@ PT_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 // dot(a,b) = (ax*bx + ay*by) + az*bz — the builtin definition shared with the oracle
 PT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// Three IEEE divisions by ONE denominator (normalize :137,:365,:397; the sphere / lens normal :160,:248).
+// hipcc expands a correctly rounded a / d into
+//     ds = div_scale(d, d, a); as = div_scale(a, d, a); r = rcp(ds); e = fma(-ds, r, 1); r = fma(e, r, r);
+//     q = as * r; t = fma(-ds, q, as); q = fma(t, r, q); t = fma(-ds, q, as); q = div_fmas(t, r, q); div_fixup(q, d, a)
+// (11 instructions, 43 issue cycles per SIMD measured — profiles/r02_valu_microbench.md).  div_scale only rescales
+// operands whose quotient or reciprocal would leave the normal range, div_fmas is a plain fma when nothing was
+// scaled, and div_fixup only replaces the result for zero / infinite / NaN operands.  For operands safely inside
+// the normal range (|a| in [2^-90, 2^60] — in particular a != 0 — and |d| in [2^-30, 2^30]: exponent difference
+// in (-126, 96), numerator exponent field > 23, 1/d normal) the expansion is therefore EXACTLY the plain sequence
+// below, and its reciprocal part (rcp and two fma) depends on the denominator only: computed once and shared by
+// the three numerators — the same operations with the same operands, hence the same bits, in 18 instead of 33
+// instructions.  If any active lane of the wave is outside that range the whole wave takes the compiler's
+// divisions (same bits for the in-range lanes, so the choice of path never shows in the result).
+// tests/test_gpu_units.py::test_div3_is_three_ieee_divisions compares the two paths on 2^28 operand sets.
+#ifndef PT_DIV3
+#define PT_DIV3 0  // A/B on MI355X: bit-identical, 31 % fewer v_rcp and 15 % fewer fma issued, kernel time unchanged (C2 2.424 vs 2.418 ms)
+#endif
+PT_DEV bool div3_in_range(V3 a, float d) {
+    uint32_t ax = __float_as_uint(a.x) & 0x7FFFFFFFu, ay = __float_as_uint(a.y) & 0x7FFFFFFFu,
+             az = __float_as_uint(a.z) & 0x7FFFFFFFu, ad = __float_as_uint(d) & 0x7FFFFFFFu;
+    uint32_t lo = min(min(ax, ay), az), hi = max(max(ax, ay), az);
+    // 2^-90 = 0x12800000, 2^60 = 0x5D800000, 2^-30 = 0x30800000, 2^30 = 0x4E800000 (NaN / inf patterns are above all of them)
+    return lo >= 0x12800000u && hi <= 0x5D800000u && ad >= 0x30800000u && ad <= 0x4E800000u;
+}
+PT_DEV float div_shared(float a, float nd, float r) {
+    float q = a * r;
+    float t = __builtin_fmaf(nd, q, a);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(nd, q, a);
+    return __builtin_fmaf(t, r, q);
+}
+PT_DEV V3 div3(V3 a, float d) {
+    if (PT_DIV3 && __all(div3_in_range(a, d))) {
+        float nd = -d;
+        float r = __builtin_amdgcn_rcpf(d);
+        float e = __builtin_fmaf(nd, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        return V3{div_shared(a.x, nd, r), div_shared(a.y, nd, r), div_shared(a.z, nd, r)};
+    }
+    return a / d;
+}
 // normalize(v) = v / sqrt(dot(v,v)); sqrtf and '/' are correctly rounded in HIP
 // (-fhip-fp32-correctly-rounded-divide-sqrt is the default and is passed explicitly)
-PT_DEV V3 normalize(V3 a) { return a / sqrtf(dot(a, a)); }
+PT_DEV V3 normalize(V3 a) { return div3(a, sqrtf(dot(a, a))); }
 PT_DEV V3 vmin(V3 a, V3 b) { return V3{b.x < a.x ? b.x : a.x, b.y < a.y ? b.y : a.y, b.z < a.z ? b.z : a.z}; }
 PT_DEV float sign1(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f)); }
 PT_DEV float pow5(float x) {
@@ -825,7 +866,7 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
             rad = which == 0 ? l.r1 : l.r2;
             hit.mat = l.mat_ID;
         }
-        hit.n = (hit.p - centre) / rad;
+        hit.n = div3(hit.p - centre, rad);
     }
     return true;
 }

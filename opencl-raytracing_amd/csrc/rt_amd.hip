@@ -34,7 +34,28 @@ struct FrameParams {
     uint32_t slot_begin, slot_end;  // owned pixel slots handled by this launch
     uint32_t first, count;          // samples first .. first+count-1
     uint32_t group_log2;            // lanes per pixel = 1 << group_log2 (<= 64)
+    uint32_t seg_cap;               // live list: entries per segment (see LIVE_SEGMENTS)
 };
+
+// The live list (pixels that need per-sample work) can be kept in LIVE_SEGMENTS independent segments, workgroup b
+// of pt_prefix appending to segment b mod LIVE_SEGMENTS and the sample kernels dealing their waves over the
+// segments.  Built to take the append counter off a single address; measured on MI355X (profiles/r02_experiments.md):
+// pt_prefix 0.198 → 0.075 ms, but pt_samples_q 2.35 → 2.75 (4 segments) … 3.07 ms (64) on C2 and 10.8 → 14.8 ms on
+// C3 — the waves of a workgroup (and neighbouring workgroups) then work on distant parts of the image, finish at
+// different times and hold their workgroup's LDS and wave slots until the slowest is through.  The list's ORDER
+// is a performance property: 1 segment ships, and the counter is relieved by one atomic per workgroup instead.
+#ifndef LIVE_SEGMENTS
+#define LIVE_SEGMENTS 1u
+#endif
+#define LIVE_COUNT_STRIDE 32u   // counters 128 bytes apart: one L2 line each
+// wave (or pixel group) `unit` of a sample kernel → its segment, its first entry and how many of `want` exist
+PT_DEV uint32_t live_take(const FrameParams &fp, const uint32_t *__restrict__ live_count, uint32_t unit, uint32_t want,
+                          uint32_t &first) {
+    uint32_t seg = unit % LIVE_SEGMENTS, start = (unit / LIVE_SEGMENTS) * want;
+    uint32_t cnt = live_count[seg * LIVE_COUNT_STRIDE];
+    first = seg * fp.seg_cap + start;
+    return start < cnt ? min(want, cnt - start) : 0u;
+}
 
 // owned pixel slot → frame coordinates.  Slots enumerate this rank's tiles
 // (t = rank, rank+world, ...) tile after tile, row-major inside a tile.
@@ -184,18 +205,28 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
         }
     }
     // append live pixels — slot index and record, both at the pixel's position in the live list, so the
-    // sample kernels read records without an indirection: one atomic per wave (order is irrelevant to the result)
+    // sample kernels read records without an indirection.  ONE atomic per WORKGROUP: the four waves' counts meet
+    // in LDS, thread 0 reserves the workgroup's run, each wave takes its part of it.  (One atomic per wave made
+    // 32 400 waves of a 1080p frame queue on a single address: 0.12 of the kernel's 0.20 ms.  Spreading the list
+    // over LIVE_SEGMENTS > 1 independent counters removes the queue too, but costs pt_samples_q 13–26 %: the
+    // list's ORDER matters to it — see LIVE_SEGMENTS.)  Order within the list is irrelevant to the result.
+    __shared__ uint32_t s_wave_n[4], s_base;
     unsigned long long m = __ballot(is_live);
-    if (m) {
-        uint32_t lane = threadIdx.x & 63u, n = (uint32_t)__popcll(m);
-        uint32_t base = 0;
-        if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(live_count, n);
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (is_live) {
-            uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            live[pos] = slot;
-            recs[pos] = rec;
-        }
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 0) s_wave_n[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
+        s_base = total ? atomicAdd(&live_count[(blockIdx.x % LIVE_SEGMENTS) * LIVE_COUNT_STRIDE], total) : 0u;
+    }
+    __syncthreads();
+    if (is_live) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wv; k++) before += s_wave_n[k];
+        uint32_t pos = (blockIdx.x % LIVE_SEGMENTS) * fp.seg_cap + s_base + before +
+                       (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        live[pos] = slot;
+        recs[pos] = rec;
     }
     flush_counters<COUNT>(cn, counters, fp.count);  // the prefix stands for `count` samples' worth of work
 }
@@ -218,14 +249,14 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
     uint32_t g = 1u << fp.group_log2;
     uint32_t li = tid >> fp.group_log2;
     uint32_t lane = tid & (g - 1u);
-    uint32_t n_live = *live_count;
-    bool valid = li < n_live;
+    uint32_t entry = 0;
+    bool valid = live_take(fp, live_count, li, 1u, entry) != 0u;
     uint32_t x = 0, y = 0;
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     if (valid) {
-        uint32_t slot = live[li];
+        uint32_t slot = live[entry];
         (void)slot_to_pixel(fp, slot, x, y);
-        PixelRec rec = recs[li];
+        PixelRec rec = recs[entry];
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
@@ -279,9 +310,10 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 // Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES(_ACCEL) workgroups resident (6: 160 KB / 6 per
 // workgroup); when that leaves a wave fewer than 384 samples (256 spp and up: the queue's tail grows) the
 // budget of 5 resident workgroups is used instead — the kernel's 80 VGPRs fit either way.
-__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, uint32_t static_float4) {
-    auto fit = [&](uint32_t workgroups) {
-        uint32_t per_wave = (163840u / workgroups - static_float4 * (uint32_t)sizeof(float4)) / 4u - 15u;
+__host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, uint32_t static_float4, uint32_t block_waves = 4u) {
+    auto fit = [&](uint32_t waves_per_simd) {
+        uint32_t workgroups = waves_per_simd * 4u / block_waves;  // resident workgroups per CU
+        uint32_t per_wave = (163840u / workgroups - static_float4 * (uint32_t)sizeof(float4)) / block_waves - 15u;
         uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
@@ -293,8 +325,12 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
     }
     return p < 1u ? 1u : p;
 }
+#ifndef PT_Q_BLOCK_WAVES
+#define PT_Q_BLOCK_WAVES 1  // waves per workgroup of pt_samples_q (they share only the staged materials): a wave that is through frees
+                            // its LDS and wave slot at once instead of waiting for three others (A/B on C2: 4 → 2.42 ms, 2 → 2.42, 1 → 2.34)
+#endif
 template <bool COUNT, bool ACCEL, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, unsigned long long *counters,
@@ -310,7 +346,9 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
     c.lsph = stage_spheres(sc, s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count));
 #endif
 
-#if PT_UNIFORM_WAVE
+#if PT_Q_BLOCK_WAVES == 1
+    const uint32_t wave = 0u, lane = threadIdx.x;
+#elif PT_UNIFORM_WAVE
     // the wave index is wave-uniform, which the compiler cannot see: this puts everything derived from it in SGPRs
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
 #else
@@ -322,9 +360,8 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
     float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
-    const uint32_t n_live = *live_count;
-    const uint32_t pix0 = (blockIdx.x * 4u + wave) * pixels_per_wave;
-    const uint32_t npix = pix0 < n_live ? min(pixels_per_wave, n_live - pix0) : 0u;
+    uint32_t pix0 = 0;
+    const uint32_t npix = live_take(fp, live_count, blockIdx.x * (uint32_t)PT_Q_BLOCK_WAVES + wave, pixels_per_wave, pix0);
     const uint32_t count = fp.count, total = npix * count;
     const float4 *rec = s_rec;
     const uint32_t *xy = s_xy;
@@ -410,6 +447,12 @@ __global__ __launch_bounds__(256, WAVES) void pt_samples_q(DeviceScene sc, Frame
             continue;  // every candidate was a final-colour pixel: keep draining the queue
         }
         PT_STAMP(c, 0);
+#ifdef PT_EXP_PAD  // timing experiment: PT_EXP_PAD extra independent full-rate VALU instructions per iteration — an
+                   // issue-bound loop slows down in proportion, a latency-bound one does not
+#pragma unroll
+        for (int k = 0; k < PT_EXP_PAD / 4; k++)
+            asm volatile("v_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0" : "+v"(idx));  // identity on a live register: no extra VGPR
+#endif
 #ifdef PT_QSTAT  // diagnostic: lane-iterations used / offered (read through rt_get_debug_counters on a BVH-free scene)
         if (COUNT) {
             uint32_t na = (uint32_t)__popcll(__ballot(active));
@@ -518,9 +561,8 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
     float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
-    const uint32_t n_live = *live_count;
-    const uint32_t pix0 = (blockIdx.x * 4u + wave) * pixels_per_wave;
-    const uint32_t npix = pix0 < n_live ? min(pixels_per_wave, n_live - pix0) : 0u;
+    uint32_t pix0 = 0;
+    const uint32_t npix = live_take(fp, live_count, blockIdx.x * 4u + wave, pixels_per_wave, pix0);
     const uint32_t count = fp.count, total = npix * count;
     const float4 *rec = s_rec;
     const uint32_t *xy = s_xy;
@@ -1187,6 +1229,7 @@ FrameParams frame_params(const rt_context *ctx, const float cam[12], uint32_t fi
     fp.first = first;
     fp.count = count;
     fp.group_log2 = glog2;
+    fp.seg_cap = 0;
     return fp;
 }
 
@@ -1215,8 +1258,10 @@ int ensure_slots(rt_context *ctx, size_t slots) {
     ctx->d_recs = nullptr;
     ctx->d_live = nullptr;
     ctx->slot_capacity = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_recs, slots * sizeof(PixelRec)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_live, (slots + 1) * sizeof(uint32_t)));
+    // segmented live list: LIVE_SEGMENTS segments of whole workgroups' worth of entries, then the segment counters
+    size_t entries = slots + (size_t)LIVE_SEGMENTS * 256u;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_recs, entries * sizeof(PixelRec)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_live, (entries + (size_t)LIVE_SEGMENTS * LIVE_COUNT_STRIDE) * sizeof(uint32_t)));
     ctx->slot_capacity = slots;
     return RT_OK;
 }
@@ -1258,7 +1303,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
     if (slots == 0) return RT_OK;
     int rc = ensure_slots(ctx, slots);
     if (rc) return rc;
-    uint32_t *live_count = ctx->d_live + ctx->slot_capacity;
+    uint32_t *live_count = ctx->d_live + ctx->slot_capacity + (size_t)LIVE_SEGMENTS * 256u;
     uint32_t slots_per_launch = ctx->max_threads_per_launch >> glog2;
     if (slots_per_launch == 0) slots_per_launch = 1;
     hipEvent_t *evp = ctx->ev[ctx->ev_count % rt_context::EV_RING];
@@ -1267,21 +1312,26 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         fp.slot_begin = b;
         fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
         uint32_t n = fp.slot_end - fp.slot_begin;
-        HIP_TRY(ctx, hipMemsetAsync(live_count, 0, sizeof(uint32_t), ctx->stream));
-        dim3 block(256), grid1((n + 255) / 256), grid2((unsigned)((((uint64_t)n << glog2) + 255) / 256));
+        HIP_TRY(ctx, hipMemsetAsync(live_count, 0, (size_t)LIVE_SEGMENTS * LIVE_COUNT_STRIDE * sizeof(uint32_t), ctx->stream));
+        // workgroup b of pt_prefix appends to segment b mod LIVE_SEGMENTS: a segment holds at most seg_cap entries
+        const uint32_t prefix_blocks = (n + 255) / 256;
+        fp.seg_cap = ((prefix_blocks + LIVE_SEGMENTS - 1) / LIVE_SEGMENTS) * 256u;
+        // sample kernels deal their waves (pixel groups) over the segments: unit u → segment u mod LIVE_SEGMENTS
+        auto units_for = [&](uint32_t per_unit) { return LIVE_SEGMENTS * ((fp.seg_cap + per_unit - 1) / per_unit); };
+        dim3 block(256), grid1(prefix_blocks), grid2((unsigned)((((uint64_t)units_for(1u) << glog2) + 255) / 256));
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
         uint32_t static_f4 = lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
         const bool sphere_bvh_only = sc.bvh_node_count != 0 && sc.mesh_bvh_root == nullptr;
         const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
-        uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4);
-        dim3 gridq((n + 4 * ppw - 1) / (4 * ppw));
+        uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
+        dim3 gridq((units_for(ppw) + PT_Q_BLOCK_WAVES - 1) / PT_Q_BLOCK_WAVES), blockq(64 * PT_Q_BLOCK_WAVES);
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
-        size_t lds_q = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw, count);
+        size_t lds_q = static_f4 * sizeof(float4) + PT_Q_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
 #define PT_CALL_QUEUE_W(C, A, W) \
-    hipLaunchKernelGGL((pt_samples_q<C, A, W>), gridq, block, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+    hipLaunchKernelGGL((pt_samples_q<C, A, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
 #define PT_CALL_QUEUE(C, A)                                                            \
     do {                                                                               \
         if (!(A)) PT_CALL_QUEUE_W(C, false, PT_Q_WAVES);                               \
@@ -1296,7 +1346,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
             // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
             uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4);
             size_t lds_w = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw_w, count);
-            dim3 gridw((n + 4 * ppw_w - 1) / (4 * ppw_w));
+            dim3 gridw((units_for(ppw_w) + 3) / 4);
             if (ctx->walk_jobs.n == 1)
                 hipLaunchKernelGGL(pt_samples_w<false>, gridw, block, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
                                    ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u);

@@ -170,7 +170,7 @@ class RayTracer:
         if isinstance(scene, str):
             path = scene
             scene = SceneCreator()
-            scene.loadScene(path, base_dir=os.path.dirname(os.path.dirname(os.path.abspath(path))))
+            scene.loadScene(path)
             scene.loadTextures()
         self.setScene(scene)
 

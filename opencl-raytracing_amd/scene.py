@@ -96,6 +96,9 @@ class SceneCreator:
         self.texture_uv = np.zeros((0, 2), dtype=f32)
         self.indices = np.zeros(0, dtype=np.uint32)
         self.texture_paths = []
+        self.model_dirs = []   # directories of the OBJ files loaded so far (texture lookup)
+        self.scene_dir = ""
+        self.base_dir = ""
         self.textures = None  # (layers, h, w, 4) float32
         self._mesh_count_total = 0  # `static cl_uint mesh_count_total`, src/scene.cpp:193
         self._keep = None
@@ -192,6 +195,9 @@ class SceneCreator:
             raise SceneError("ERROR: Assimp: Unable to open file \"%s\"." % path)
         textured = int(self.materials["type"][mat_ID]) == _abi.T_TEXTURED
         meshes = _read_obj(path)
+        d = os.path.dirname(path) or "."
+        if d not in self.model_dirs:
+            self.model_dirs.append(d)
         for pos, uv, idx, tex_path in meshes:
             # transformVertex, src/scene.cpp:226-232: column-major mat4 × (x,y,z,1)
             m = transform
@@ -207,7 +213,33 @@ class SceneCreator:
             self.addMesh(out, uv, idx, tex_id)
         self.addModel(len(meshes), mat_ID)
 
-    # -- src/scene.cpp:145-190 (stb_image replaced by PIL; RGB^2.2, alpha linear) ----
+    # -- src/scene.cpp:145-190 ------------------------------------------------------
+    @staticmethod
+    def _ldr_to_hdr_tables():
+        """stb_image's 8-bit → float rule (stbi__ldr_to_hdr, default gamma 2.2f / scale 1.0f — what
+        stbi_loadf applies, src/scene.cpp:158): colour = (float)pow(byte / 255.0f, 2.2f) with a FLOAT
+        quotient and the float constant 2.2f promoted to double for pow(); alpha = byte / 255.0f.
+        stb_image is not in the reference tree, so this restates its published formula (parity
+        unpinned).  math.pow is libm's pow, as in the C++ mirror (host/scene.cpp)."""
+        import math
+        q = (np.arange(256, dtype=f32) / f32(255.0)).astype(f32)
+        g = float(f32(2.2))
+        colour = np.array([math.pow(float(x), g) for x in q], dtype=np.float64).astype(f32)
+        return colour, q
+
+    def _texture_dirs(self, search_dirs):
+        """Where a texture is looked up by BASE NAME when its map_Kd path does not exist as written —
+        the reference's own .mtl files name an absolute path on the author's machine
+        (assets/cube/cube.mtl:13).  Same order as host/scene.cpp."""
+        dirs = []
+        for d in list(search_dirs) + [os.path.join(m, "..", "textures") for m in self.model_dirs] + \
+                list(self.model_dirs) + ([os.path.join(self.scene_dir, "..", "textures")] if self.scene_dir else []) + \
+                [os.path.join("assets", "textures")] + \
+                ([os.path.join(self.base_dir, "textures"), self.base_dir] if self.base_dir else []):
+            if d not in dirs:
+                dirs.append(d)
+        return dirs
+
     def loadTextures(self, search_dirs=()):
         if len(self.models) == 0:
             self.textures = None
@@ -215,19 +247,26 @@ class SceneCreator:
         if not self.texture_paths:
             raise SceneError("ERROR: TEXTURE COUNT = 0")
         from PIL import Image
+        colour, alpha = self._ldr_to_hdr_tables()
         layers = []
         for p in self.texture_paths:
-            cand = [p] + [os.path.join(d, os.path.basename(p.replace("\\", "/"))) for d in search_dirs]
+            pn = p.replace("\\", "/")
+            cand = [p]
+            if not os.path.isabs(pn):
+                cand += ([os.path.join(self.base_dir, pn)] if self.base_dir else []) + \
+                        [os.path.join(m, pn) for m in self.model_dirs]
+            cand += [os.path.join(d, os.path.basename(pn)) for d in self._texture_dirs(search_dirs)]
             found = next((c for c in cand if os.path.isfile(c)), None)
             if found is None:
-                raise SceneError("ERROR: STBimage: COULD NOT FIND THE TEXTURE")
+                raise SceneError("ERROR: STBimage: COULD NOT FIND THE TEXTURE: " + p)
             im = Image.open(found)
             if im.mode != "RGBA":
                 raise SceneError("ERROR: STBimage: TEXTURE HAS A WRONG FORMAT: %d INSTEAD OF 4 (RGBA)" %
                                  len(im.getbands()))
-            a = np.asarray(im, dtype=np.float64) / 255.0
-            a[..., :3] = a[..., :3] ** 2.2
-            a = a.astype(f32)
+            px = np.asarray(im, dtype=np.uint8)
+            a = np.empty(px.shape, dtype=f32)
+            a[..., :3] = colour[px[..., :3]]
+            a[..., 3] = alpha[px[..., 3]]
             if layers and a.shape != layers[0].shape:
                 raise SceneError("ERROR: TEXTURES HAVE DIFFERENT SIZES")
             layers.append(a)
@@ -242,14 +281,30 @@ class SceneCreator:
 
     # -- src/scene.cpp:297-403 ------------------------------------------------------
     def loadScene(self, path, base_dir=None):
+        """``load:`` paths are used as written — relative to the working directory, like the
+        reference (src/scene.cpp:355 → :195; its scene file says "assets/cube/cube.obj") — and only
+        when that file does not exist against ``base_dir`` (default: the parent of the scene's
+        directory, assets/scenes/x.scene → assets/) and the scene's own directory."""
         try:
             with open(path, "r") as fh:
                 text = fh.read()
         except OSError as e:
             raise SceneError("ERROR: SCENE: NOT SUCCESFULLY READ: " + str(e))
-        self.loadSceneText(text, base_dir if base_dir is not None else "")
+        self.scene_dir = os.path.dirname(path)
+        if base_dir is None:
+            base_dir = os.path.dirname(self.scene_dir)
+        self.loadSceneText(text, base_dir)
+
+    def _resolve_model_path(self, p):
+        if os.path.isfile(p) or os.path.isabs(p):
+            return p
+        for d in (self.base_dir, self.scene_dir):
+            if d and os.path.isfile(os.path.join(d, p)):
+                return os.path.join(d, p)
+        return p
 
     def loadSceneText(self, text, base_dir=""):
+        self.base_dir = base_dir or ""
         mode = None
         model = _identity()
         for line in text.split("\n"):
@@ -276,7 +331,7 @@ class SceneCreator:
                     elif word == "load":
                         p = it.path()
                         mat = it.uint()
-                        self.loadModel(os.path.join(base_dir, p) if base_dir else p, mat, model)
+                        self.loadModel(self._resolve_model_path(p), mat, model)
                         model = _identity()
                     # other words with a colon inside MODELS are ignored by the reference
                 else:

@@ -8,7 +8,10 @@ this module; the product package never does.
   Reference()  _ref/libref.so — the unmodified reference kernel compiled for
                x86-64 (build container only; absent on the GPU box unless the
                prebuilt file travelled).
-Both take the product's host-side scene object (anything with .desc() and
+  ReferenceGfx950()  _ref_gfx950/ — the same kernel file built for gfx950 with ROCm's REAL OpenCL
+               builtin library and run on the GPU through the HIP module API (GPU box only;
+               measurement tool of DESIGN.md §3, no pass/fail parity test depends on it).
+All take the product's host-side scene object (anything with .desc() and
 .texture_args(), i.e. opencl-raytracing_amd.scene.SceneCreator) so that oracle and
 GPU are fed byte-identical inputs.
 """
@@ -21,6 +24,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libref.so")
+REF950_SO = os.path.join(HERE, "_ref_gfx950", "libref950.so")
+REF950_HSACO = os.path.join(HERE, "_ref_gfx950", "ref950.hsaco")
+REF950_HSACO_NOCONTRACT = os.path.join(HERE, "_ref_gfx950", "ref950_nocontract.hsaco")
 
 COUNTER_FIELDS = ("samples", "bounces", "t_sphere", "t_plane", "t_lens", "t_model", "t_mesh", "t_tri", "h_tri",
                   "h_bounce", "n_scatter", "n_dielectric", "n_texfetch", "image_reads")
@@ -180,3 +186,34 @@ class Reference(_Base):
         sd = self._scene_args(scene)[0]
         assert self.lib.ref_hit_triangle(sd, _fp(rays), _fp(mesh), _fp(face), C.c_size_t(len(mesh)), _fp(out)) == 0
         return out
+
+
+class ReferenceGfx950(_Base):
+    """The reference's kernel file as ROCm's OpenCL tool chain builds it for gfx950 (real builtin
+    library: fma-contracted dot, rsq-based normalize, rcp-based divide), executed on the GPU.
+    One process can hold ONE code object (the default build, or the -ffp-contract=off build)."""
+
+    @staticmethod
+    def available(hsaco=REF950_HSACO):
+        return os.path.isfile(REF950_SO) and os.path.isfile(hsaco)
+
+    def __init__(self, hsaco=REF950_HSACO, device=0):
+        self.lib = C.CDLL(REF950_SO)
+        self.lib.ref950_last_error.restype = C.c_char_p
+        if self.lib.ref950_open(hsaco.encode(), device):
+            raise RuntimeError(self.lib.ref950_last_error().decode())
+
+    def render(self, scene, cam, table, w, h, first, count, want_last=False):
+        """→ (sum over samples first..first+count-1 of the LINEAR radiance, h×w×4 with the count in .w,
+        and optionally the last sample's own frame)."""
+        if scene.texture_args()[3]:
+            raise ValueError("textured scenes need an OpenCL image object; not supported by this tool")
+        acc = np.zeros((h, w, 4), dtype=np.float32)
+        last = np.zeros((h, w, 4), dtype=np.float32) if want_last else None
+        sd = self._scene_args(scene)[0]
+        cam, table = _f32(cam), _f32(table)
+        rc = self.lib.ref950_render(sd, _fp(cam), _fp(table), w, h, C.c_uint32(first), C.c_uint32(count), _fp(acc),
+                                    _fp(last) if want_last else None)
+        if rc:
+            raise RuntimeError(self.lib.ref950_last_error().decode())
+        return (acc, last) if want_last else acc

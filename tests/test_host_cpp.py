@@ -59,8 +59,102 @@ def test_cpp_scene_arrays_match_python(built, scene, tmp_path):
     assert np.array_equal(camblock.view(np.uint32), pycam.view(np.uint32))
     if tex is not None:
         assert tex.shape == s.textures.shape
-        # PNG via PIL (RGBA) vs PPM via the C++ reader: same 8-bit texels, same RGB^2.2 rule
-        assert np.allclose(tex, s.textures, rtol=2e-7, atol=0)
+        # PNG decoded by PIL vs by the C++ reader (zlib + scanline filters): same 8-bit texels, and the same
+        # stb_image rule (float)pow(byte / 255.0f, 2.2f) through libm's pow in both mirrors → same bits
+        assert np.array_equal(tex.view(np.uint32), s.textures.view(np.uint32))
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "assets", "scenes", "scene.scene")),
+                    reason="the reference tree exists in the build container only")
+def test_reference_scene_tree_loads_unchanged(built, tmp_path):
+    """The reference's own scene file, OBJ/MTL cubes and RGBA PNGs, read where they lie with the working
+    directory at the reference's root (its `load:` paths are CWD-relative, src/scene.cpp:355 → :195; its .mtl
+    files name an absolute path on the author's machine, assets/cube/cube.mtl:13): both mirrors must accept
+    the tree as it is and produce byte-identical arrays.  Nothing is copied into the repo."""
+    out = str(tmp_path / "ref.bin")
+    subprocess.run([CLI, "--scene", "assets/scenes/scene.scene", "--dump-scene", out, "--size", "1200x800"],
+                   check=True, cwd=REF)
+    raw = open(out, "rb").read()
+    counts = np.frombuffer(raw, np.uint32, 12)
+    # materials, spheres, planes, lenses, vertices, uvs, indices, meshes, models, tex w, h, layers
+    assert list(counts) == [9, 8, 1, 1, 48, 48, 72, 2, 2, 1024, 1024, 2]
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        s = rt.SceneCreator()
+        s.loadScene("assets/scenes/scene.scene")
+        s.loadTextures()
+    finally:
+        os.chdir(cwd)
+    a = rt._abi
+    off = 96
+    for name, arr, dt in (("materials", s.materials, a.MATERIAL), ("spheres", s.spheres, a.SPHERE),
+                          ("planes", s.planes, a.PLANE), ("lenses", s.lenses, a.LENS),
+                          ("vertices", s.vertices, np.dtype(("<f4", 4))), ("uvs", s.texture_uv, np.dtype(("<f4", 2))),
+                          ("indices", s.indices, np.dtype("<u4")), ("meshes", s.meshes, a.MESH),
+                          ("models", s.models, a.MODEL)):
+        n = len(arr) * dt.itemsize
+        assert raw[off:off + n] == np.ascontiguousarray(arr).tobytes(), name
+        off += n
+    tex = np.frombuffer(raw, np.float32, 2 * 1024 * 1024 * 4, off).reshape(2, 1024, 1024, 4)
+    assert np.array_equal(tex.view(np.uint32), s.textures.view(np.uint32))
+    assert [os.path.basename(p) for p in s.texture_paths] == ["die.png", "die2.png"]
+    # what the importer must yield for the cubes (SURVEY §8f row 2): one vertex per face corner, 12 triangles each
+    assert list(s.meshes["face_count"]) == [12, 12] and list(s.meshes["texture_ID"]) == [0, 1]
+    assert 0.0 <= float(s.textures.min()) and float(s.textures.max()) <= 1.0
+
+
+def test_png_reader_rejects_non_rgba(built, tmp_path):
+    """src/scene.cpp:165-179: a texture must have 4 channels."""
+    from PIL import Image
+    os.makedirs(tmp_path / "m")
+    Image.fromarray(np.full((4, 4, 3), 128, np.uint8), "RGB").save(str(tmp_path / "m" / "t.png"))
+    (tmp_path / "m" / "b.mtl").write_text("newmtl s\nmap_Kd t.png\n")
+    (tmp_path / "m" / "b.obj").write_text("mtllib b.mtl\nusemtl s\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
+                                           "f 1/1 2/2 3/3\n")
+    (tmp_path / "s.scene").write_text('MATERIALS:\ntextured, (1, 1, 1), 1\nMODELS:\nload: "m/b.obj", 0\n')
+    p = subprocess.run([CLI, "--scene", str(tmp_path / "s.scene"), "--dump-scene", str(tmp_path / "o.bin")],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode != 0 and "3 INSTEAD OF 4 (RGBA)" in p.stderr, p.stderr
+    s = rt.SceneCreator()
+    s.loadScene(str(tmp_path / "s.scene"))
+    with pytest.raises(rt.SceneError, match="3 INSTEAD OF 4"):
+        s.loadTextures()
+
+
+def test_png_reader_all_filters(built, tmp_path):
+    """The C++ PNG reader against PIL on an image that makes the encoder use every scanline filter."""
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    img = np.zeros((64, 48, 4), np.uint8)
+    img[:16] = rng.randint(0, 256, (16, 48, 4))                                   # noise
+    img[16:32] = np.linspace(0, 255, 48).astype(np.uint8)[None, :, None]          # horizontal ramp (Sub)
+    img[32:48] = np.linspace(0, 255, 16).astype(np.uint8)[:, None, None]          # vertical ramp (Up)
+    img[48:] = (np.add.outer(np.arange(16), np.arange(48)) * 3 % 256).astype(np.uint8)[..., None]  # diagonal (Paeth/Avg)
+    os.makedirs(tmp_path / "m")
+    Image.fromarray(img, "RGBA").save(str(tmp_path / "m" / "t.png"), optimize=True)
+    (tmp_path / "m" / "b.mtl").write_text("newmtl s\nmap_Kd t.png\n")
+    (tmp_path / "m" / "b.obj").write_text("mtllib b.mtl\nusemtl s\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
+                                           "f 1/1 2/2 3/3\n")
+    (tmp_path / "s.scene").write_text('MATERIALS:\ntextured, (1, 1, 1), 1\nMODELS:\nload: "m/b.obj", 0\n')
+    out = str(tmp_path / "o.bin")
+    subprocess.run([CLI, "--scene", str(tmp_path / "s.scene"), "--dump-scene", out], check=True, cwd=str(tmp_path))
+    raw = open(out, "rb").read()
+    counts = np.frombuffer(raw, np.uint32, 12)
+    assert list(counts[9:12]) == [48, 64, 1]
+    tex = np.frombuffer(raw, np.float32, 48 * 64 * 4, len(raw) - 48 * 64 * 16).reshape(64, 48, 4)
+    s = rt.SceneCreator()
+    s.loadScene(str(tmp_path / "s.scene"))
+    s.loadTextures()
+    assert np.array_equal(tex.view(np.uint32), s.textures[0].view(np.uint32))
+    # the rule itself: colour = (float)pow(byte / 255.0f, 2.2f), alpha = byte / 255.0f
+    q = (img.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    assert np.array_equal(tex[..., 3], q[..., 3])
+    exp = np.power(q[..., :3].astype(np.float64), float(np.float32(2.2))).astype(np.float32)
+    assert np.abs(tex[..., :3].view(np.int32) - exp.view(np.int32)).max() <= 1
 
 
 def test_cpp_scene_errors(built, tmp_path):

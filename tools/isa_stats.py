@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""tools/isa_stats.py [kernel-substring ...] — static ISA statistics of the shipped gfx950 kernels.
+
+Compiles csrc/rt_amd.hip for the device only (-S, the flags of __graft_entry__.HIP_FLAGS) and prints, per
+kernel: VGPRs / SGPRs / scratch bytes / spilled VGPRs from the code-object metadata and the static opcode
+histogram grouped into the issue-cost classes measured by tools/valu_microbench.hip
+(profiles/r02_valu_microbench.md).  --json dumps everything for bench.py / profile summaries."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# issue cost in cycles per wave64 instruction per SIMD (profiles/r02_valu_microbench.md, 8 waves/SIMD, wall clock)
+FULL, MOV, HALF, TRANS = 2.0, 3.0, 4.0, 8.0
+
+
+def cost_class(op):
+    """→ (class name, cycles) for a VALU opcode; None for non-VALU."""
+    if not op.startswith("v_"):
+        return None
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_", base):
+        return ("trans", TRANS)
+    if base.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr")):
+        return ("mov", MOV)
+    if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|fmaak|fmamk)_f32", base) or \
+       re.match(r"v_(add|sub|subrev|addc|subb|subbrev)(_co)?_u32", base) or re.match(r"v_(and|or|xor|not)_b32", base) or \
+       base.startswith("v_cndmask_b32"):
+        return ("full", FULL)
+    return ("half", HALF)   # f64, packed f32, integer multiply, shifts, compares, conversions, min/max, div helpers, lane reads
+
+
+def device_asm(force=False):
+    import __graft_entry__ as g
+    extra = os.environ.get("ISA_EXTRA_FLAGS", "").split()   # e.g. ISA_EXTRA_FLAGS="-DPT_Q_BLOCK_WAVES=1" for a variant
+    tag = ("_" + "_".join(e.lstrip("-D").replace("=", "") for e in extra)) if extra else ""
+    out = os.path.join(ROOT, "build", "rt_amd_gfx950%s.s" % tag)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    srcs = g.hip_sources()
+    if force or not os.path.isfile(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        flags = [f for f in g.HIP_FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.check_call([g.HIPCC] + flags + extra + ["--cuda-device-only", "-S", srcs[0], "-o", out],
+                              stderr=subprocess.DEVNULL)
+    return out
+
+
+def demangle(names):
+    p = subprocess.run(["c++filt"] + names, capture_output=True, text=True)
+    return [re.sub(r"\(.*", "", l.replace("void ", "")) for l in p.stdout.strip().split("\n")]
+
+
+def kernels(path):
+    text = open(path).read()
+    meta = {}
+    md = text[text.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in text else ""
+    for blk in re.split(r"^  - \.", md, flags=re.M)[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", blk)
+        if not nm:
+            continue
+        get = lambda k: int(re.search(r"%s:\s+(\d+)" % k, blk).group(1)) if re.search(r"%s:\s+(\d+)" % k, blk) else 0
+        meta[nm.group(1)] = dict(vgpr=get("vgpr_count"), sgpr=get("sgpr_count"), scratch=get("private_segment_fixed_size"),
+                                 spilled_vgprs=get("vgpr_spill_count"), lds_static=get("group_segment_fixed_size"))
+    out = collections.OrderedDict()
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if name not in meta:
+            continue
+        ops = collections.Counter()
+        for line in body.split("\n"):
+            t = line.strip().split()
+            if t and re.match(r"^[vs]_|^ds_|^global_|^scratch_|^buffer_|^flat_", t[0]):
+                ops[t[0]] += 1
+        out[name] = dict(meta[name], ops=ops)
+    names = list(out)
+    for n, d in zip(names, demangle(names)):
+        out[n]["demangled"] = d
+    return out
+
+
+def summarize(k):
+    ops = k["ops"]
+    cls = collections.Counter()
+    cyc = collections.Counter()
+    for op, n in ops.items():
+        c = cost_class(op)
+        if c:
+            cls[c[0]] += n
+            cyc[c[0]] += n * c[1]
+    valu = sum(cls.values())
+    return dict(valu=valu, classes=dict(cls), cycles=dict(cyc),
+                salu=sum(n for o, n in ops.items() if o.startswith("s_") and not o.startswith(("s_load", "s_waitcnt", "s_nop", "s_buffer"))),
+                smem=sum(n for o, n in ops.items() if o.startswith(("s_load", "s_buffer"))),
+                vmem=sum(n for o, n in ops.items() if o.startswith(("global_", "buffer_", "flat_"))),
+                scratch_ops=sum(n for o, n in ops.items() if o.startswith("scratch_")),
+                lds=sum(n for o, n in ops.items() if o.startswith("ds_")))
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    ks = kernels(device_asm("--force" in sys.argv))
+    if "--json" in sys.argv:
+        print(json.dumps({k["demangled"]: dict(summarize(k), vgpr=k["vgpr"], sgpr=k["sgpr"], scratch=k["scratch"],
+                                               spilled_vgprs=k["spilled_vgprs"]) for k in ks.values()}, indent=1))
+        sys.exit(0)
+    for k in ks.values():
+        if args and not any(a in k["demangled"] for a in args):
+            continue
+        s = summarize(k)
+        print("%-44s vgpr %3d sgpr %3d scratch %3d B (%d spilled)  VALU %5d  SALU %5d  SMEM %3d  VMEM %3d  scratch-ops %3d  LDS %3d" %
+              (k["demangled"], k["vgpr"], k["sgpr"], k["scratch"], k["spilled_vgprs"], s["valu"], s["salu"], s["smem"],
+               s["vmem"], s["scratch_ops"], s["lds"]))
+        if args:
+            print("   classes:", {c: "%d (%.0f%%)" % (n, 100.0 * n / s["valu"]) for c, n in s["classes"].items()})
+            top = [(o, n) for o, n in k["ops"].most_common() if o.startswith("v_")]
+            print("   " + "  ".join("%s:%d" % (o, n) for o, n in top))

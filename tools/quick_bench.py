@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""Kernel-time survey over workloads (GPU box): tools/quick_bench.py c2:64 c3:256 c4:2 c5:2"""
-import os, sys, time
+"""Kernel-time survey over workloads and library variants (GPU box):
+    tools/quick_bench.py [--lib=PATH] [--queue=0|1] c2:64 c3:256 c4:2 c5:2[:W:H]
+Prints the best of 5 HIP-event times of the fused trace call and a hash of the accumulator (every
+variant of the library must print the same hash for the same spec: results never depend on tuning)."""
+import hashlib
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import opencl_raytracing_amd as rt
 
 args = sys.argv[1:]
+lib = "default"
 if args and args[0].startswith("--lib="):
-    rt.load_library(args.pop(0)[6:])
+    lib = args.pop(0)[6:]
+    rt.load_library(lib)
 queue = None
 if args and args[0].startswith("--queue="):
     queue = int(args.pop(0)[8:])
@@ -22,9 +29,11 @@ for spec in args:
     if queue is not None:
         t.setOption(t.OPT_SAMPLE_QUEUE, queue)
     t.clear(); t.renderSamples(wl.camera, 0, spp); t.sync()
+    digest = hashlib.sha1(t.readLinear().tobytes()).hexdigest()[:12]
     ms = []
-    for _ in range(3):
+    for _ in range(5):
         t.clear(); t.renderSamples(wl.camera, 0, spp); t.sync(); ms.append(t.lastKernelMs())
     n = wl.width * wl.height * spp
-    print("%-4s %dx%d spp %-4d kernel %.3f ms  %.1f Msamples/s" % (name, wl.width, wl.height, spp, min(ms), n / min(ms) / 1e3), flush=True)
+    print("%-28s %-4s %dx%d spp %-4d kernel %8.3f ms  %9.1f Msamples/s  image %s" %
+          (os.path.basename(lib), name, wl.width, wl.height, spp, min(ms), n / min(ms) / 1e3, digest), flush=True)
     t.close()
