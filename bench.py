@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X path tracer.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5] [--scaling strong|weak]
 
-Metric (BASELINE.json): Msamples/s at 1920×1080, 64 spp, and the fraction of the
-HBM roofline.  One *step* = one pass of the hot path over one frame: clear,
-ONE fused launch tracing every pixel-sample of the frame (samples 0..spp-1 of
-every pixel), resolve to the gamma image, and — for N > 1 — the RCCL reduce of
-the tile-sharded radiance buffer to rank 0.  Scene, camera block and random
-table are resident in HBM before the timed region starts.
+Metric (BASELINE.json): Msamples/s (pixel-samples = camera paths per second), with the roofline
+fraction of the dominant kernel.  One *step* = one pass of the hot path over one frame: clear, ONE
+fused trace call over every pixel-sample of the frame (pt_prefix + pt_samples_q / pt_samples_w),
+resolve to the gamma image and — for N > 1 — the exchange of the tile-sharded radiance buffer to
+rank 0 over RCCL.  Scene, camera block and random table are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the 1920×1080 frame
-is cut into 8×8 tiles interleaved over ranks; per-GPU work is held fixed (weak
-scaling) by giving every pixel 64·N samples, so each rank traces 132.7 M
-pixel-samples per step exactly as at N = 1.  value = pixel-samples all ranks traced
-÷ max-over-ranks wall time.
+Workload per N (BASELINE.json `configs`):
+  N = 1        C2, the configuration the metric is quoted on: 8 spheres + plane, 1920x1080, 64 spp.
+  N = 2, 4, 8  C4 by default — 100 000 spheres + plane, 1920x1080, 64 spp, "tile-sharded 2/4/8 x MI355X":
+               STRONG scaling, the same frame cut into 8x8 tiles interleaved over the ranks
+               (`--workload c5` is BASELINE's 8-GPU configuration).  The line also carries the same
+               workload's single-GPU step time, measured by rank 0 in the same run outside the timed
+               region, so that the speed-up can be read from one line.
+  --scaling weak   the round-1 form: C2 with 64 x N samples per pixel, per-GPU work fixed — issued as N
+               calls of 64 samples, so every rank runs the very kernels of the N = 1 line.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: "roofline" (algorithmic bytes of the reference kernel per launch ÷ the
-kernel's HIP-event duration, against the 8 TB/s HBM peak) and "cpu_baseline" (the
-oracle / compiled reference kernel timed on this host's cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  "roofline"     VALU issue: the kernels are bound by vector-instruction issue, not by HBM.
+                 achieved = issue cycles of the dominant kernel per launch (rocprofv3 SQ_INSTS_VALU_* class
+                 counts x the issue cost of each class measured on this chip, profiles/valu_mix.json)
+                 / that kernel's HIP-event duration measured live here; peak = 1024 SIMDs x 2.4 GHz.
+                 hbm_frac (counter bytes / time / 8 TB/s) and the round-1 algorithmic-bytes figure
+                 (labelled non-physical) ride along.
+  "parity"       untimed: probes of the measured configuration AND a crop of the resolved timed frame
+                 against the oracle.
+  "cpu_baseline" the oracle (CPU restatement of the reference kernel) on this host's cores, bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,13 +40,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS = 1024               # 256 CUs x 4 SIMD-32
+PEAK_CLOCK_GHZ = 2.4
 WORKLOAD_DESC = {
-    "c2": "C2 Cornell-style: 8 spheres + 1 plane, 1920x1080, 64 spp",
-    "c3": "C3 textured 12-triangle cube + 4 spheres, 1920x1080, 256 spp",
-    "c4": "C4 100k random spheres + plane, 1920x1080, 64 spp",
-    "c5": "C5 50k-triangle dielectric mesh, 3840x2160, 512 spp",
+    "c2": "C2 Cornell-style: 8 spheres + 1 plane",
+    "c3": "C3 textured 12-triangle cube + 4 spheres",
+    "c4": "C4 100k random spheres + plane",
+    "c5": "C5 50k-triangle dielectric mesh",
 }
+# dominant kernel of one fused trace call, per workload (what `roofline` prices), and its first stage
+KERNELS = {"c2": ("pt_samples_q<false, false", "pt_prefix<false, false>"),
+           "c3": ("pt_samples_q<false, false", "pt_prefix<false, false>"),
+           "c4": ("pt_samples_q<false, true", "pt_prefix<false, true>"),
+           "c5": ("pt_samples_w<false>", "pt_prefix<false, true>")}
+CROP = {"c2": (900, 330, 32, 16), "c3": (930, 300, 32, 16), "c4": (960, 270, 8, 4), "c5": (1900, 900, 4, 2)}
 
 
 def host_cores():
@@ -52,13 +70,22 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def source_digest():
+    """Digest of the device sources: profiles/valu_mix.json records the one it was measured on."""
+    import __graft_entry__ as g
+    h = hashlib.sha1()
+    for p in g.hip_sources():
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(wl, table, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload: whole rows of the
     frame, all `spp` samples per pixel, as many rows as ~budget_s of CPU work allows
-    (calibrated on a thin slice), spread over the frame.  Uses oracle/_ref (the
-    compiled reference kernel) when that library is present, else the oracle port."""
+    (calibrated on a thin slice), spread over the frame.  The checker is the oracle port
+    (oracle/pt_oracle.c); where the compiled reference kernel (oracle/_ref) is present —
+    the build container — that is timed instead."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     from oracle import Oracle, Reference
     threads = host_cores()
     kind = "reference" if Reference.available() else "port"
@@ -80,7 +107,7 @@ def cpu_baseline(wl, table, budget_s=20.0):
     rows = min(threads, H)
 
     def bands(n, cw):
-        """n bands of `rows` rows × cw columns, spread evenly from top to bottom (sky, horizon, floor)."""
+        """n bands of `rows` rows x cw columns, spread evenly from top to bottom (sky, horizon, floor)."""
         x0 = (W - cw) // 2
         return [(x0, int(i * (H - rows) / max(n - 1, 1)) if n > 1 else (H - rows) // 2, cw, rows) for i in range(n)]
 
@@ -108,17 +135,77 @@ def cpu_baseline(wl, table, budget_s=20.0):
                       "%.1f s wall" % (nb, rows, cw_s, W, H, spp_s, spp, samples / 1e6, wall)}
 
 
+def roofline(workload, main_ms, first_ms, call_ms, alg_bytes):
+    """VALU-issue roofline of the dominant kernel from profiles/valu_mix.json (class counts per launch x
+    measured issue costs) and the kernel's live HIP-event time; see tools/summarize_profile.py."""
+    peak = SIMDS * PEAK_CLOCK_GHZ                                   # G issue cycles / s
+    out = {"bound": "valu", "achieved": None, "peak": round(peak, 1),
+           "unit": "G VALU issue cycles/s (1024 SIMD-32 x 2.4 GHz; a wave64 instruction occupies its SIMD for 2 "
+                   "(fp32 add/mul/fma, int add, logic), 4 (fp64, int mul, shifts, compares, conversions, min/max, "
+                   "division helpers, lane reads) or 8 (rcp/sqrt/rsq) cycles: profiles/r02_valu_microbench.md)",
+           "frac": None, "traffic": None, "kernel_ms": round(main_ms, 4), "first_stage_ms": round(first_ms, 4),
+           "call_ms": round(call_ms, 4)}
+    path = os.path.join(ROOT, "profiles", "valu_mix.json")
+    mix = None
+    if os.path.isfile(path):
+        try:
+            mix = json.load(open(path)).get(workload)
+        except Exception:
+            mix = None
+    main_key, first_key = KERNELS[workload]
+    kern = None
+    if mix:
+        for name, k in mix.get("kernels", {}).items():
+            if name.startswith(main_key):
+                kern, out["kernel"] = k, name
+    t = main_ms * 1e-3
+    if kern:
+        ach = kern["issue_cycles"] / t / 1e9
+        lanes = kern.get("lanes_per_inst")
+        out.update({
+            "achieved": round(ach, 1), "frac": round(ach / peak, 4),
+            "frac_bounds": [round(kern["issue_cycles_low"] / t / 1e9 / peak, 4),
+                            round(min(kern["issue_cycles_high"] / t / 1e9 / peak, 1.0), 4)],
+            "lanes": round(lanes / 64.0, 4) if lanes else None,
+            "useful_lane_frac": round(ach / peak * lanes / 64.0, 4) if lanes else None,
+            "issue_cycles_per_launch": int(kern["issue_cycles"]), "valu_insts_per_launch": int(kern["valu_insts"]),
+            "cycles_per_valu_inst_per_simd": round(t * PEAK_CLOCK_GHZ * 1e9 * SIMDS / kern["valu_insts"], 3),
+            "profile": mix.get("profile"), "profile_kernel_ms": kern.get("kernel_ms_profiled"),
+            "profile_matches_source": mix.get("source_digest") == source_digest(),
+            "scratch_bytes": kern.get("scratch_bytes"), "vgpr": kern.get("vgpr"),
+        })
+        hbm = sum(k["hbm_bytes"] or 0 for k in mix["kernels"].values())
+        if hbm:
+            out["traffic"] = int(hbm)
+            out["hbm_frac"] = round(hbm / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    else:
+        out["note"] = "profiles/valu_mix.json has no entry for this workload: run tools/profile.sh + tools/summarize_profile.py"
+    # round 1's figure, kept for continuity: the REFERENCE kernel's logical traffic (every primitive struct it
+    # would have dereferenced) over the call time.  The scene lives in SGPRs / L2, so these bytes never move:
+    # not a physical rate, and not bounded by 1.
+    out["alg_hbm_frac"] = {"value": round(alg_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "algorithmic_bytes_per_launch": int(alg_bytes),
+                           "note": "non-physical: reference's brute-force logical bytes / time / 8 TB/s (SURVEY 8d)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC))
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOAD_DESC),
+                    help="default: c2 at N = 1, c4 (BASELINE's tile-sharded configuration) at N > 1")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1: strong (default) = the same frame sharded; weak = C2 with 64 x N spp in N calls")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--workload-arg", action="append", default=[], metavar="KEY=INT",
+                    help="rehearsals only: override a generator argument of the workload, e.g. n_spheres=20000")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N>1: gather of packed tiles (default) or full-frame RCCL reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-single-gpu-reference", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg")
     args = ap.parse_args()
 
@@ -138,11 +225,16 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
-    wl = rt.workloads.get(args.workload)
+    scaling = args.scaling if args.scaling != "auto" else "strong"
+    workload = args.workload or ("c2" if world == 1 or scaling == "weak" else "c4")
+    wl_args = {k: int(v) for k, v in (a.split("=", 1) for a in args.workload_arg)}
+    wl = rt.workloads.get(workload, **wl_args)
     base_spp = args.spp or wl.spp
-    spp = base_spp * world                       # weak scaling: per-GPU pixel-samples fixed
+    spp = base_spp * world if scaling == "weak" else base_spp
+    chunk = base_spp                                 # samples per fused call: the kernels of the N = 1 line
     tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
-    renderer = dist_mod.ShardedRenderer(dist_mod.GpuShard(tracer, rank, world), rank, world, exchange=args.exchange)
+    shard = dist_mod.GpuShard(tracer, rank, world, chunk=chunk)
+    renderer = dist_mod.ShardedRenderer(shard, rank, world, exchange=args.exchange)
     table = tracer.getRandomTable() if rank == 0 else None
 
     def step():
@@ -158,7 +250,7 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     # algorithmic bytes of one launch: exact work counters from the counting build (untimed)
-    note("counting pass")
+    note("counting pass (%s, %d rank(s), %s scaling)" % (workload, world, scaling))
     tracer.enableCounters(True)
     tracer.resetCounters()
     step()
@@ -177,10 +269,12 @@ def main():
         step()
     fence()
     wall = time.perf_counter() - t0
-    # per-launch kernel duration over the timed region: the library records a HIP event
-    # pair on the launch stream around every trace launch; read them back afterwards
-    ev_ms = tracer.kernelMsHistory(min(args.steps, 64))
-    launch_ms = float(np.mean(ev_ms))
+    # per-launch kernel durations over the timed region: the library records HIP events on the launch stream
+    # around every fused call and between its two stages; they are only read back here
+    calls = min(args.steps * (spp // chunk), 64)
+    ev_ms = tracer.kernelMsHistory(calls)
+    first_ms, main_ms = tracer.stageMsHistory(calls)
+    call_ms = float(np.mean(ev_ms))
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     s = torch.tensor([float(my_samples)], dtype=torch.float64, device="cuda")
@@ -189,54 +283,70 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
     wall_max, total_samples = float(t.item()), float(s.item())
 
+    # strong scaling: the same workload on ONE GPU, by rank 0, outside the timed region
+    single = None
+    if world > 1 and scaling == "strong" and not args.no_single_gpu_reference:
+        if rank == 0:
+            note("single-GPU reference of the same workload (untimed leg)")
+            solo = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
+            n_solo = 3 if workload in ("c4", "c5") else 10
+            solo.renderFrameOnDevice(wl.camera, spp)
+            solo.sync()
+            t1 = time.perf_counter()
+            for _ in range(n_solo):
+                solo.renderFrameOnDevice(wl.camera, spp)
+            solo.sync()
+            single = (time.perf_counter() - t1) / n_solo * 1e3
+            solo.close()
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         value = total_samples * args.steps / wall_max / 1e6
-        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        flops = 17 * cn.t_sphere + 11 * cn.t_plane + 60 * cn.t_lens + 35 * cn.t_tri + 60 * cn.h_bounce
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.isfile(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": "Msamples/sec (rays/sec) at 1920x1080, 64 spp; % HBM roofline",
+            "metric": "Msamples/sec (rays/sec) at %dx%d, %d spp; fraction of the roofline that binds (VALU issue)" %
+                      (wl.width, wl.height, spp),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_DESC[args.workload], "width": wl.width, "height": wl.height,
-                       "spp_per_gpu": base_spp, "spp_total": spp, "sharding": "8x8 tiles interleaved over %d rank(s)"
-                       % world + ("; RCCL %s of the radiance buffer to rank 0" % args.exchange if world > 1 else ""),
-                       "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "pt_prefix + %s (one fused trace call)" % ("pt_samples_w" if args.workload == "c5" else "pt_samples_q"), "kernel_ms": round(launch_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "bytes_per_pixel_sample": round(alg_bytes / max(my_samples, 1), 1),
-                         "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
-                         # SURVEY §8d's side figure: useful fp32 work of the REFERENCE's loops at its per-test
-                         # flop counts (sphere 17, plane 11, lens 60, triangle 35, shading 60 per hit) against the
-                         # vector peak without FMA (the parity contract forbids contraction): 157.3 / 2 TFLOP/s
-                         "valu": {"flop_per_launch_est": int(flops), "achieved": round(flops / (launch_ms * 1e-3) / 1e12, 2),
-                                  "peak": 78.6, "unit": "TFLOP/s (fp32 vector, no FMA)",
-                                  "frac": round(flops / (launch_ms * 1e-3) / 1e12 / 78.6, 4)}},
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %dx%d, %d spp" % (WORKLOAD_DESC[workload], wl.width, wl.height, spp),
+                       "width": wl.width, "height": wl.height, "spp_per_call": chunk, "spp_total": spp,
+                       "sharding": "8x8 tiles interleaved over %d rank(s)" % world +
+                                   ("; %s of the packed radiance tiles to rank 0 over RCCL" % args.exchange if world > 1 else ""),
+                       "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED),
+                       **({"workload_overrides": wl_args} if wl_args else {})},
+            "roofline": roofline(workload, float(np.mean(main_ms)), float(np.mean(first_ms)), call_ms, alg_bytes),
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
+            "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
         }
+        if single is not None:
+            out["single_gpu_same_workload"] = {"ms_per_step": round(single, 4),
+                                               "value": round(total_samples / (single * 1e-3) / 1e6, 2),
+                                               "speedup": round(single / ms_per_step, 3),
+                                               "note": "rank 0 alone, same frame, same run, outside the timed region"}
         if world == 1 and not args.no_parity_check:
-            # untimed sanity leg: the configuration just measured computes the reference's radiance —
-            # probes of the frame against the oracle (checker only, never the thing measured)
-            note("parity probes")
+            # untimed sanity leg: the configuration just measured computes the reference's radiance.
+            # (1) per pixel-sample probes, bit for bit; (2) a crop of the RESOLVED TIMED FRAME (what pt_prefix +
+            # the sample kernel left in the image buffer) against the oracle's progressive image, 1e-4 relative.
+            note("parity: probes + crop of the timed frame")
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from oracle import Oracle
+            orc = Oracle()
             rng = np.random.RandomState(1)
-            n = 64 if args.workload in ("c4", "c5") else 2000
+            n = 64 if workload in ("c4", "c5") else 2000
             xs, ys, ss = rng.randint(0, wl.width, n), rng.randint(0, wl.height, n), rng.randint(0, spp, n)
             got = tracer.traceSamples(wl.camera, xs, ys, ss)
-            exp, _ = Oracle().samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
+            exp, _ = orc.samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
             same = int((got.view(np.uint32) == exp.view(np.uint32)).all(axis=1).sum())
-            out["parity"] = {"probes": n, "bit_exact": same, "checker": "oracle/pt_oracle.c"}
+            x0, y0, cw, ch = CROP[workload]
+            frame = renderer.image()                  # the last timed step's image
+            ref, _ = orc.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=spp, region=(x0, y0, cw, ch),
+                                threads=host_cores())
+            a, b = frame[y0:y0 + ch, x0:x0 + cw], ref[y0:y0 + ch, x0:x0 + cw]
+            dev = float((np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max())
+            out["parity"] = {"probes": n, "bit_exact": same, "checker": "oracle/pt_oracle.c",
+                             "timed_frame_crop": [x0, y0, cw, ch], "crop_max_rel_dev": dev, "crop_ok": dev <= 1e-4,
+                             "crop_lit_fraction": float((b[..., :3].sum(-1) > 0).mean())}
         if not args.no_cpu_baseline and world == 1:
             note("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* error codes */
 #define RT_OK 0
@@ -353,6 +353,29 @@ int rt_last_kernel_ms(rt_context *ctx, float *ms);
 /* The same for the last *n_out <= min(cap, 64) render calls, oldest first.  The
  * events are only read here, so a timed loop can run without per-step syncs. */
 int rt_kernel_ms_history(rt_context *ctx, float *ms, size_t cap, size_t *n_out);
+
+/* ---- unit probes of the device routines (test instrumentation; no reference counterpart) ----
+ * rt_debug_hit: one intersection routine per record, through the same search + winner rebuild the
+ * trace kernels inline.  kind 0 hitSphere (raytracer.cl:149), 1 hitPlane (:176), 2 hitLens (:196),
+ * 3 hitScene (:322), 4 hitTriangle (:257) on face[i] of mesh prim[i].  rays: n × 6 floats (origin,
+ * direction); out12: n × 12 floats {hit, t, p.xyz, normal.xyz, uv.xy, texture_ID bits, mat_ID bits},
+ * all zero on a miss — the record layout of oracle/ref_shim.cpp ref_hit.
+ * rt_debug_material: routine 0 rayReflect (:362), 1 rayRefract (:369), 2 rayScatter (:393),
+ * 3 rayRefractDielectric (:407).  in16: n × 16 floats {ray dir.xyz, hit p.xyz, hit normal.xyz,
+ * colour so far.xyz, mat_ID bits, s_seed bits, pixel x bits, pixel y bits}; out9: n × 9 floats
+ * {new origin.xyz, new direction.xyz, colour.xyz} (getCol's mixCol is not part of the routines).
+ * rt_debug_div3: in4 n × {a.xyz, d} → out6 n × {shared-reciprocal a/d, compiler's a/d}. */
+int rt_debug_hit(rt_context *ctx, int kind, const float *rays, const uint32_t *prim, const uint32_t *face, size_t n,
+                 float *out12);
+int rt_debug_material(rt_context *ctx, int routine, const float *in16, size_t n, float *out9);
+int rt_debug_div3(rt_context *ctx, const float *in4, size_t n, float *out6);
+
+/* The two stages of the same calls separately: a fused rt_render_spp call is pt_prefix
+ * (first_ms: one work-item per pixel, the sample-invariant path prefix) followed by the
+ * per-sample kernel (second_ms: pt_samples_q / pt_samples_w, the dominant kernel that
+ * bench.py prices against the roofline); a third event is recorded between them.  Calls
+ * on the direct path (rt_render, rt_render_again) report first_ms = 0. */
+int rt_stage_ms_history(rt_context *ctx, float *first_ms, float *second_ms, size_t cap, size_t *n_out);
 
 /* Name, CU count and arch of the context's device, e.g. "gfx950". */
 int rt_device_info(rt_context *ctx, char *name, size_t name_len, int *cu_count, char *arch, size_t arch_len);

@@ -792,6 +792,125 @@ __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, 
     out[3 * i + 2] = col.z;
 }
 
+// ---- unit probes of the device routines (tests only; rt_debug_hit / rt_debug_material / rt_debug_div3) -----------
+// One work-item per record; the routines are the very ones the trace kernels inline (hit_primitives' sphere_t /
+// plane_t / lens_t, triangle_t, hit_scene + hit_finish, scatter), so a unit vector that matches the oracle here
+// pins the arithmetic of the hot loop piece by piece (SURVEY §8c "unit vectors").  Record layouts are those of
+// oracle/ref_shim.cpp ref_hit / ref_material.
+PT_DEV void put_hit(float *o, bool hit, float t, const Hit &h) {
+    for (int k = 0; k < 12; k++) o[k] = 0.0f;
+    if (!hit) return;
+    o[0] = 1.0f; o[1] = t;
+    o[2] = h.p.x; o[3] = h.p.y; o[4] = h.p.z;
+    o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
+    o[8] = h.u; o[9] = h.v;
+    o[10] = __uint_as_float(h.tex);
+    o[11] = __uint_as_float(h.mat);
+}
+template <bool ACCEL>
+__global__ __launch_bounds__(256) void pt_debug_hit(DeviceScene sc, int kind, const float *__restrict__ rays,
+                                                    const uint32_t *__restrict__ prim, const uint32_t *__restrict__ face,
+                                                    uint32_t n, float *__restrict__ out) {
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
+    Ctx c{sc, stage_materials(sc, s_mat), nullptr};
+    c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    r.d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Hit h;
+    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.tex = h.mat = 0;
+    Nearest nb;
+    bool hit = false;
+    if (kind == 3) {                      // hitScene :322-360
+        hit = hit_scene<false, ACCEL>(c, r, h);
+        if (hit) { hit_primitives<false, ACCEL>(c, r, nb); hit_models<false, ACCEL>(c, r, nb); }
+    } else {
+        // a single primitive through the SAME (t, id) search + winner rebuild the trace kernels use
+        uint32_t p = prim[i];
+        float t = -1.0f;
+        if (kind == 0) { const rt_sphere &sp = sc.spheres[p]; t = sphere_t(r, make_float4(sp.pos.x, sp.pos.y, sp.pos.z, sp.r * sp.r)); nb.id = K_SPHERE | p; }
+        else if (kind == 1) { const rt_plane &pl = sc.planes[p]; t = plane_t(r, ld3(pl.pos), ld3(pl.normal)); nb.id = K_PLANE | p; }
+        else if (kind == 2) { int which; t = lens_t(r, sc.lenses[p], &which); nb.id = K_LENS | p; }
+        else if (kind == 4) {             // hitTriangle :257-289 on face face[i] of mesh p
+            const float4 *fr = sc.faces + 3u * ((size_t)sc.mesh_face_base[p] + face[i]);
+            float4 q0 = fr[0], q1 = fr[1];
+            float4 q2 = fr[2];
+            float u, v;
+            t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
+            nb.id = K_MESH | p; nb.face = face[i]; nb.u = u; nb.v = v; nb.mat = 0;
+        }
+        if (t > 0.0f) {
+            nb.t = t;
+            hit = hit_finish<false>(c, r, nb, h);
+            if (kind == 4) h.mat = 0;     // hitTriangle does not set mat_ID (hitModel does, :314)
+        }
+    }
+    put_hit(out + 12 * (size_t)i, hit, nb.t, h);
+}
+
+__global__ __launch_bounds__(256) void pt_debug_material(DeviceScene sc, int routine, const float *__restrict__ in,
+                                                         uint32_t n, float *__restrict__ out) {
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
+    Ctx c{sc, stage_materials(sc, s_mat), nullptr};
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float *v = in + 16 * (size_t)i;
+    Ray r;
+    r.o = mk(0.0f, 0.0f, 0.0f);
+    r.d = mk(v[0], v[1], v[2]);
+    Hit h;
+    h.p = mk(v[3], v[4], v[5]);
+    h.n = mk(v[6], v[7], v[8]);
+    h.u = h.v = 0.0f;
+    h.tex = 0;
+    h.mat = __float_as_uint(v[12]);
+    V3 out_col = mk(v[9], v[10], v[11]);
+    uint32_t seed = __float_as_uint(v[13]), gx = __float_as_uint(v[14]), gy = __float_as_uint(v[15]);
+    int type;
+    float extra;
+    V3 col;
+    load_material(c, h.mat, type, extra, col);
+    // the routine under test decides the branch of scatter(); the material supplies extra_data and — for
+    // rayReflect's "*= extra only if t_reflective" (:366) — its own type
+    int as_type = routine == 0 ? (type == RT_REFLECTIVE ? RT_REFLECTIVE : -1) : routine == 1 ? RT_REFRACTIVE
+                  : routine == 2 ? RT_DIFFUSE : RT_DIELECTRIC;
+    Rnd rnd = fetch_rnd(sc.table, r.d, seed, gx, gy);
+    if (as_type == -1) {   // rayReflect on a material that is not t_reflective: the reflection tail of scatter()
+        float k = 2.0f * dot(r.d, h.n);
+        r.o = h.p;
+        r.d = normalize(r.d - h.n * k);
+    } else {
+        scatter<false>(c, r, out_col, h, as_type, extra, mk(INFINITY, INFINITY, INFINITY), rnd);  // mixCol with +inf = identity
+    }
+    float *o = out + 9 * (size_t)i;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+    o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+    o[6] = out_col.x; o[7] = out_col.y; o[8] = out_col.z;
+}
+
+// div3 (shared-reciprocal form of three IEEE divisions) against the compiler's divisions: in n × 4 {a.xyz, d} →
+// out n × 6 {div3 result, a / d}; `force` = 1 runs the shared-reciprocal sequence even when PT_DIV3 is off
+__global__ __launch_bounds__(256) void pt_debug_div3(const float *__restrict__ in, uint32_t n, float *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    V3 a = mk(in[4 * i], in[4 * i + 1], in[4 * i + 2]);
+    float d = in[4 * i + 3];
+    V3 q = a / d, s = q;
+    if (div3_in_range(a, d)) {
+        float nd = -d, rr = __builtin_amdgcn_rcpf(d);
+        float e = __builtin_fmaf(nd, rr, 1.0f);
+        rr = __builtin_fmaf(e, rr, rr);
+        s = V3{div_shared(a.x, nd, rr), div_shared(a.y, nd, rr), div_shared(a.z, nd, rr)};
+    }
+    float *o = out + 6 * (size_t)i;
+    o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = q.x; o[4] = q.y; o[5] = q.z;
+}
+
 // Multi-GPU exchange: the accumulator pixels a rank owns, packed in slot order (what
 // travels over xGMI is 1/world of the frame instead of the whole frame) ...
 __global__ __launch_bounds__(256) void pt_pack(FrameParams fp, const float4 *__restrict__ accum,
@@ -1060,7 +1179,7 @@ struct rt_context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     static constexpr int EV_RING = 64;   // event pairs of the last EV_RING render calls
-    hipEvent_t ev[EV_RING][2] = {};
+    hipEvent_t ev[EV_RING][3] = {};      // [0] before the call, [1] after it, [2] between the fused call's two stages
     uint64_t ev_count = 0;
     std::string error;
     std::string dev_name, dev_arch;
@@ -1279,6 +1398,7 @@ int launch_render(rt_context *ctx, const float cam[12], uint32_t first, uint32_t
     if (slots_per_launch == 0) slots_per_launch = 1;
     hipEvent_t *evp = ctx->ev[ctx->ev_count % rt_context::EV_RING];
     HIP_TRY(ctx, hipEventRecord(evp[0], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // no first stage on the direct path
     for (uint32_t b = 0; b < slots; b += slots_per_launch) {
         fp.slot_begin = b;
         fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
@@ -1342,6 +1462,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
         bool accel_on = scene_has_accel(sc);
         PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
+        HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // (the last slot range's; one range is the normal case)
         if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
             // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
             uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4);
@@ -1425,7 +1546,7 @@ int rt_create(int device, int width, int height, rt_context **out) {
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->error = "hipStreamCreate failed"; return bail(RT_EHIP); }
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < rt_context::EV_RING; i++)
-        if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
+        if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess || hipEventCreate(&ctx->ev[i][2]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
     if (hipMalloc((void **)&ctx->d_counters, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
@@ -1459,7 +1580,7 @@ void rt_destroy(rt_context *ctx) {
     ctx->bvh_sph.release();
     ctx->bvh_idx.release();
     for (int i = 0; i < rt_context::EV_RING; i++)
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < 3; k++)
             if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -2036,6 +2157,95 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
     return RT_OK;
 }
 
+extern "C++" {
+namespace {
+// upload `bytes` of input, run `launch(d_in, d_out)`, download `out_bytes`
+template <class F>
+int debug_roundtrip(rt_context *ctx, const void *in, size_t bytes, void *out, size_t out_bytes, F launch) {
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_in, bytes ? bytes : 16));
+    if (hipMalloc(&d_out, out_bytes ? out_bytes : 16) != hipSuccess) { (void)hipFree(d_in); return fail(ctx, RT_EHIP, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { launch(d_in, d_out); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RT_EHIP, "debug probe: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int rt_debug_hit(rt_context *ctx, int kind, const float *rays, const uint32_t *prim, const uint32_t *face, size_t n,
+                 float *out12) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->have_scene) return fail(ctx, RT_ESTATE, "no scene: call rt_set_scene first");
+    if (n == 0) return RT_OK;
+    if (!rays || !out12 || kind < 0 || kind > 4 || n > (1u << 26) || (kind != 3 && !prim) || (kind == 4 && !face))
+        return fail(ctx, RT_EINVAL, "bad unit-probe arguments");
+    const size_t counts[5] = {ctx->spheres.n, ctx->planes.n, ctx->lenses.n, 0, ctx->meshes.n};
+    std::vector<uint32_t> pf(2 * n, 0u);
+    for (size_t i = 0; i < n; i++) {
+        if (kind != 3) {
+            if (prim[i] >= counts[kind]) return fail(ctx, RT_ERANGE, "unit probe %zu: primitive %u does not exist", i, prim[i]);
+            pf[i] = prim[i];
+        }
+        if (kind == 4) pf[n + i] = face[i];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (kind == 4) {  // face indices against the meshes' face counts (host copy of the mesh array)
+        std::vector<rt_mesh> meshes(ctx->meshes.n);
+        HIP_TRY(ctx, hipMemcpy(meshes.data(), ctx->meshes.p, meshes.size() * sizeof(rt_mesh), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++)
+            if (face[i] >= meshes[prim[i]].face_count) return fail(ctx, RT_ERANGE, "unit probe %zu: face %u does not exist", i, face[i]);
+    }
+    // rays and (prim, face) travel in one buffer: 6 floats + 2 words per record
+    std::vector<uint32_t> in(8 * n);
+    memcpy(in.data(), rays, 6 * n * sizeof(float));
+    memcpy(in.data() + 6 * n, pf.data(), 2 * n * sizeof(uint32_t));
+    DeviceScene sc = device_scene(ctx);
+    return debug_roundtrip(ctx, in.data(), in.size() * 4, out12, 12 * n * sizeof(float), [&](void *d_in, void *d_out) {
+        const float *d_rays = (const float *)d_in;
+        const uint32_t *d_prim = (const uint32_t *)d_in + 6 * n, *d_face = d_prim + n;
+        dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        if (scene_has_accel(sc))
+            hipLaunchKernelGGL(pt_debug_hit<true>, grid, block, 0, ctx->stream, sc, kind, d_rays, d_prim, d_face, (uint32_t)n, (float *)d_out);
+        else
+            hipLaunchKernelGGL(pt_debug_hit<false>, grid, block, 0, ctx->stream, sc, kind, d_rays, d_prim, d_face, (uint32_t)n, (float *)d_out);
+    });
+}
+
+int rt_debug_material(rt_context *ctx, int routine, const float *in16, size_t n, float *out9) {
+    if (!ctx) return RT_EINVAL;
+    if (!ctx->have_scene) return fail(ctx, RT_ESTATE, "no scene: call rt_set_scene first");
+    if (n == 0) return RT_OK;
+    if (!in16 || !out9 || routine < 0 || routine > 3 || n > (1u << 26)) return fail(ctx, RT_EINVAL, "bad unit-probe arguments");
+    for (size_t i = 0; i < n; i++) {
+        uint32_t w[4];
+        memcpy(w, in16 + 16 * i + 12, sizeof w);
+        if (w[0] >= ctx->materials.n) return fail(ctx, RT_ERANGE, "unit probe %zu: material %u does not exist", i, w[0]);
+        if (w[1] > RT_MAX_SAMPLE + RT_DEPTH || w[2] >= RT_MAX_DIM || w[3] >= RT_MAX_DIM)
+            return fail(ctx, RT_EINVAL, "unit probe %zu: seed / pixel outside the supported range", i);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceScene sc = device_scene(ctx);
+    return debug_roundtrip(ctx, in16, 16 * n * sizeof(float), out9, 9 * n * sizeof(float), [&](void *d_in, void *d_out) {
+        hipLaunchKernelGGL(pt_debug_material, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, routine,
+                           (const float *)d_in, (uint32_t)n, (float *)d_out);
+    });
+}
+
+int rt_debug_div3(rt_context *ctx, const float *in4, size_t n, float *out6) {
+    if (!ctx || !in4 || !out6 || n > (1u << 28)) return RT_EINVAL;
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return debug_roundtrip(ctx, in4, 4 * n * sizeof(float), out6, 6 * n * sizeof(float), [&](void *d_in, void *d_out) {
+        hipLaunchKernelGGL(pt_debug_div3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_in,
+                           (uint32_t)n, (float *)d_out);
+    });
+}
+
 int rt_shard_slots(rt_context *ctx, int world, uint32_t *slots_out) {
     if (!ctx || !slots_out || world < 1) return RT_EINVAL;
     uint32_t tw = 1u << ctx->tile_w_log2, th = 1u << ctx->tile_h_log2;
@@ -2152,6 +2362,21 @@ int rt_kernel_ms_history(rt_context *ctx, float *ms, size_t cap, size_t *n_out) 
         hipEvent_t *evp = ctx->ev[(ctx->ev_count - n + i) % rt_context::EV_RING];
         HIP_TRY(ctx, hipEventSynchronize(evp[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ms[i], evp[0], evp[1]));
+    }
+    *n_out = n;
+    return RT_OK;
+}
+
+int rt_stage_ms_history(rt_context *ctx, float *first_ms, float *second_ms, size_t cap, size_t *n_out) {
+    if (!ctx || !first_ms || !second_ms || !n_out) return RT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t have = ctx->ev_count < (uint64_t)rt_context::EV_RING ? (size_t)ctx->ev_count : (size_t)rt_context::EV_RING;
+    size_t n = have < cap ? have : cap;
+    for (size_t i = 0; i < n; i++) {  // oldest of the last n first
+        hipEvent_t *evp = ctx->ev[(ctx->ev_count - n + i) % rt_context::EV_RING];
+        HIP_TRY(ctx, hipEventSynchronize(evp[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&first_ms[i], evp[0], evp[2]));
+        HIP_TRY(ctx, hipEventElapsedTime(&second_ms[i], evp[2], evp[1]));
     }
     *n_out = n;
     return RT_OK;

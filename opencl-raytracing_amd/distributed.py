@@ -86,10 +86,12 @@ def reduce_frame(buf, dst=0):
 class GpuShard:
     """Adapter between ShardedRenderer and a RayTracer on this rank's GPU."""
 
-    def __init__(self, tracer, rank, world, tile=TILE):
+    def __init__(self, tracer, rank, world, tile=TILE, chunk=None):
+        """``chunk``: samples per fused trace call (None = all in one call).  bench.py's weak-scaling run gives
+        every pixel 64·N samples as N calls of 64, so each rank runs the kernels of the single-GPU line."""
         import torch
         self.torch = torch
-        self.tracer, self.rank, self.world = tracer, rank, world
+        self.tracer, self.rank, self.world, self.chunk = tracer, rank, world, chunk
         tracer.setShard(rank, world, tile, tile)
         # One dedicated (non-default) HIP stream carries the library's kernels AND is torch's
         # current stream while collectives are issued, so RCCL orders itself after the trace
@@ -108,7 +110,9 @@ class GpuShard:
 
     def trace(self, camera, first_sample, spp):
         self.tracer.clear()
-        self.tracer.renderSamples(camera, first_sample, spp)
+        step = self.chunk or spp
+        for s in range(0, spp, step):
+            self.tracer.renderSamples(camera, first_sample + s, min(step, spp - s))
 
     def pack(self, out):
         self.tracer.packAccum(out.data_ptr(), out.numel() * 4)

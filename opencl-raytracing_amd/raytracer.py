@@ -26,7 +26,7 @@ SYMBOLS = (
     "rt_set_shard", "rt_render", "rt_render_again", "rt_sample_counter", "rt_clear", "rt_render_spp", "rt_resolve",
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
-    "rt_kernel_ms_history", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
+    "rt_kernel_ms_history", "rt_stage_ms_history", "rt_debug_hit", "rt_debug_material", "rt_debug_div3", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
     "rt_get_debug_counters", "rt_debug_check_accel",
 )
 
@@ -93,6 +93,10 @@ def load_library(path=LIB_PATH):
     lib.rt_counters_bytes.restype = u64
     lib.rt_last_kernel_ms.argtypes = [vp, fp]
     lib.rt_kernel_ms_history.argtypes = [vp, fp, sz, C.POINTER(sz)]
+    lib.rt_stage_ms_history.argtypes = [vp, fp, fp, sz, C.POINTER(sz)]
+    lib.rt_debug_hit.argtypes = [vp, C.c_int, vp, vp, vp, sz, vp]
+    lib.rt_debug_material.argtypes = [vp, C.c_int, vp, sz, vp]
+    lib.rt_debug_div3.argtypes = [vp, vp, sz, vp]
     lib.rt_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.rt_shard_slots.argtypes = [vp, C.c_int, C.POINTER(u32)]
     lib.rt_pack_accum.argtypes = [vp, vp, sz]
@@ -273,6 +277,12 @@ class RayTracer:
         self.resolve()
         return self.transferImage()
 
+    def renderFrameOnDevice(self, camera, spp):
+        """clear + fused render + resolve, all enqueued, nothing read back (the image stays in HBM)."""
+        self.clear()
+        self.renderSamples(camera, 0, spp)
+        self.resolve()
+
     def traceSamples(self, camera, xs, ys, samples):
         xs = np.ascontiguousarray(xs, dtype=np.uint32)
         ys = np.ascontiguousarray(ys, dtype=np.uint32)
@@ -334,6 +344,39 @@ class RayTracer:
         got = C.c_size_t()
         self._check(self._lib.rt_kernel_ms_history(self._ctx, buf, n, C.byref(got)))
         return [buf[i] for i in range(got.value)]
+
+    def stageMsHistory(self, n=64):
+        """(first-stage ms, second-stage ms) of the last <= min(n, 64) render launches, oldest first: pt_prefix and
+        the per-sample kernel of a fused call."""
+        a, b = (C.c_float * n)(), (C.c_float * n)()
+        got = C.c_size_t()
+        self._check(self._lib.rt_stage_ms_history(self._ctx, a, b, n, C.byref(got)))
+        return [a[i] for i in range(got.value)], [b[i] for i in range(got.value)]
+
+    # -- unit probes of the device routines (tests) -------------------------------------
+    def debugHit(self, kind, rays, prim=None, face=None):
+        """kind 0 sphere, 1 plane, 2 lens, 3 scene, 4 triangle (mesh prim[i], face[i]) → n × 12 floats (rt_debug_hit)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = len(rays)
+        prim = np.zeros(n, np.uint32) if prim is None else np.ascontiguousarray(prim, dtype=np.uint32)
+        face = np.zeros(n, np.uint32) if face is None else np.ascontiguousarray(face, dtype=np.uint32)
+        out = np.zeros((n, 12), dtype=np.float32)
+        self._check(self._lib.rt_debug_hit(self._ctx, kind, rays.ctypes.data, prim.ctypes.data, face.ctypes.data, n,
+                                           out.ctypes.data))
+        return out
+
+    def debugMaterial(self, routine, vec):
+        """routine 0 rayReflect, 1 rayRefract, 2 rayScatter, 3 rayRefractDielectric on n × 16 records → n × 9 floats."""
+        vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1, 16)
+        out = np.zeros((len(vec), 9), dtype=np.float32)
+        self._check(self._lib.rt_debug_material(self._ctx, routine, vec.ctypes.data, len(vec), out.ctypes.data))
+        return out
+
+    def debugDiv3(self, vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros((len(vec), 6), dtype=np.float32)
+        self._check(self._lib.rt_debug_div3(self._ctx, vec.ctypes.data, len(vec), out.ctypes.data))
+        return out
 
     def deviceInfo(self):
         name, arch, cu = C.create_string_buffer(128), C.create_string_buffer(64), C.c_int()

@@ -125,6 +125,15 @@ class Oracle(_Base):
         assert self.lib.oracle_hit_triangle(sd, _fp(rays), _fp(mesh), _fp(face), C.c_size_t(len(mesh)), _fp(out)) == 0
         return out
 
+    def material(self, routine, scene, table, vec):
+        """routine 0 rayReflect, 1 rayRefract, 2 rayScatter, 3 rayRefractDielectric on n × 16 input records
+        (cases.material_vectors) → n × 9 floats {new origin, new dir, colour}."""
+        vec, table = _f32(vec), _f32(table)
+        out = np.zeros((len(vec), 9), dtype=np.float32)
+        sd = self._scene_args(scene)[0]
+        assert self.lib.oracle_material(routine, sd, _fp(table), _fp(vec), C.c_size_t(len(vec)), _fp(out)) == 0
+        return out
+
     def counters_bytes(self, cn):
         return int(self.lib.oracle_counters_bytes(C.byref(cn)))
 
@@ -186,6 +195,17 @@ class Reference(_Base):
         sd = self._scene_args(scene)[0]
         assert self.lib.ref_hit_triangle(sd, _fp(rays), _fp(mesh), _fp(face), C.c_size_t(len(mesh)), _fp(out)) == 0
         return out
+
+
+def _ref_material(self, routine, scene, table, vec):
+    vec, table = _f32(vec), _f32(table)
+    out = np.zeros((len(vec), 9), dtype=np.float32)
+    sd = self._scene_args(scene)[0]
+    assert self.lib.ref_material(routine, sd, _fp(table), _fp(vec), C.c_size_t(len(vec)), _fp(out)) == 0
+    return out
+
+
+Reference.material = _ref_material
 
 
 class ReferenceGfx950(_Base):

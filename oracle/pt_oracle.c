@@ -584,6 +584,45 @@ int oracle_hit_triangle(const rt_scene_desc *sc, const float *rays, const uint32
     return 0;
 }
 
+/* material routines on their own — same record layout as ref_material() in ref_shim.cpp:
+ * in n × 16 floats {dir, p, normal, colour, mat_ID bits, s_seed bits, gid0 bits, gid1 bits} → out n × 9 floats
+ * {new origin, new dir, colour}; routine 0 rayReflect :362, 1 rayRefract :369, 2 rayScatter :393,
+ * 3 rayRefractDielectric :407 */
+int oracle_material(int routine, const rt_scene_desc *sc, const float *table, const float *in, size_t n, float *out) {
+    world_t wd = make_world(1, 1, NULL, table, sc, NULL, 0, 0, 0);
+    for (size_t i = 0; i < n; i++) {
+        const float *v = in + 16 * i;
+        ray_t r;
+        r.o = V(0.0f, 0.0f, 0.0f);
+        r.d = V(v[0], v[1], v[2]);
+        hit_t h;
+        memset(&h, 0, sizeof h);
+        h.p = V(v[3], v[4], v[5]);
+        h.n = V(v[6], v[7], v[8]);
+        v3 c = V(v[9], v[10], v[11]);
+        uint32_t mat, seed, gx, gy;
+        memcpy(&mat, v + 12, 4);
+        memcpy(&seed, v + 13, 4);
+        memcpy(&gx, v + 14, 4);
+        memcpy(&gy, v + 15, 4);
+        if (mat >= sc->material_count) return -1;
+        h.mat = mat;
+        const rt_material *m = sc->materials + mat;
+        switch (routine) {
+            case 0: reflect(&r, &c, &h, m); break;
+            case 1: refract(&r, &c, &h, m); break;
+            case 2: scatter(&wd, &r, &c, &h, m, seed, gx, gy); break;
+            case 3: dielectric(&wd, &r, &c, &h, m, seed, gx, gy); break;
+            default: return -1;
+        }
+        float *o = out + 9 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+        o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+        o[6] = c.x; o[7] = c.y; o[8] = c.z;
+    }
+    return 0;
+}
+
 uint64_t oracle_counters_bytes(const rt_counters *c) {
     return 32 * c->t_sphere + 48 * c->t_plane + 64 * c->t_lens + 12 * c->t_model + 16 * c->t_mesh + 60 * c->t_tri +
            36 * c->h_tri + 48 * c->h_bounce + 12 * c->n_scatter + 4 * c->n_dielectric + 64 * c->n_texfetch +

@@ -233,6 +233,10 @@ bool hitLens(const ClRay *r, const void *l, ClHPI *hpi);
 bool hitTriangle(const ClRay *r, const ClScene *scene, const void *mesh, unsigned a, unsigned b, unsigned c,
                  ClHPI *hpi);
 bool hitScene(const ClRay *r, const ClScene *scene, ClHPI *hpi);
+void rayReflect(ClRay *r, float3 *c, const ClHPI *hpi, const ClScene *scene);
+void rayRefract(ClRay *r, float3 *c, ClHPI *hpi, const ClScene *scene);
+void rayScatter(ClRay *r, float3 *c, const ClHPI *hpi, const float *random, unsigned s_seed, const ClScene *scene);
+void rayRefractDielectric(ClRay *r, float3 *c, ClHPI *hpi, const float *random, unsigned s_seed, const ClScene *scene);
 }
 
 // ---- flat driver API ---------------------------------------------------------
@@ -393,6 +397,46 @@ int ref_hit_triangle(const rt_scene_desc *scene, const float *rays, const uint32
         bool hit = hitTriangle(&ray, &rs.cl, scene->meshes + mesh[i], 3 * face[i], 3 * face[i] + 1, 3 * face[i] + 2, &h);
         if (!hit) memset(&h, 0, sizeof h);
         put_hpi(out + 12 * i, hit, h);
+    }
+    return 0;
+}
+
+// material routines (raytracer.cl:362-435) on their own.  in: n × 16 floats
+// {ray dir.xyz, hit p.xyz, hit normal.xyz, colour so far.xyz, mat_ID bits, s_seed bits, gid0 bits, gid1 bits};
+// out: n × 9 floats {new origin.xyz, new dir.xyz, colour.xyz}.  routine: 0 rayReflect, 1 rayRefract,
+// 2 rayScatter, 3 rayRefractDielectric.  (mixCol is getCol's, not the routines': not applied.)
+int ref_material(int routine, const rt_scene_desc *scene, const float *table, const float *in, size_t n, float *out) {
+    RefScene rs;
+    build_scene(rs, scene, nullptr, 0, 0, 0);
+    for (size_t i = 0; i < n; i++) {
+        const float *v = in + 16 * i;
+        ClRay r;
+        r.origin = float3{0.0f, 0.0f, 0.0f};
+        r.dir = float3{v[0], v[1], v[2]};
+        r.param = 0.0f;
+        ClHPI h;
+        memset(&h, 0, sizeof h);
+        h.p = float3{v[3], v[4], v[5]};
+        h.normal = float3{v[6], v[7], v[8]};
+        float3 c = {v[9], v[10], v[11]};
+        unsigned seed, gx, gy;
+        memcpy(&h.mat_ID, v + 12, 4);
+        memcpy(&seed, v + 13, 4);
+        memcpy(&gx, v + 14, 4);
+        memcpy(&gy, v + 15, 4);
+        g_gid[0] = gx;
+        g_gid[1] = gy;
+        switch (routine) {
+            case 0: rayReflect(&r, &c, &h, &rs.cl); break;
+            case 1: rayRefract(&r, &c, &h, &rs.cl); break;
+            case 2: rayScatter(&r, &c, &h, table, seed, &rs.cl); break;
+            case 3: rayRefractDielectric(&r, &c, &h, table, seed, &rs.cl); break;
+            default: return -1;
+        }
+        float *o = out + 9 * i;
+        o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
+        o[3] = r.dir.x; o[4] = r.dir.y; o[5] = r.dir.z;
+        o[6] = c.x; o[7] = c.y; o[8] = c.z;
     }
     return 0;
 }

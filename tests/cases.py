@@ -27,9 +27,11 @@ CASES = {
                max_sample=64, full_frame_spp=1),
     "c3": dict(workload="c3", kw=dict(width=1920, height=1080), crop=(930, 300, 64, 48), spp=32, probes=1500,
                max_sample=256, full_frame_spp=0),
-    "c4": dict(workload="c4", kw=dict(width=1920, height=1080), crop=(960, 270, 16, 8), spp=4, probes=160,
+    # C4 / C5: full scene, full frame size, and the FULL sample counts of the timed configurations (64 / 512 spp)
+    # on a 16×8 crop — 8 192 / 65 536 reference pixel-samples through 100 000 spheres / 50 000 faces by brute force
+    "c4": dict(workload="c4", kw=dict(width=1920, height=1080), crop=(960, 270, 16, 8), spp=64, probes=160,
                max_sample=64, full_frame_spp=0),
-    "c5": dict(workload="c5", kw=dict(width=3840, height=2160), crop=(1900, 900, 16, 8), spp=4, probes=160,
+    "c5": dict(workload="c5", kw=dict(width=3840, height=2160), crop=(1900, 900, 16, 8), spp=512, probes=160,
                max_sample=512, full_frame_spp=0),
     "all_kinds": dict(workload="all_kinds", kw=dict(width=1200, height=800), crop=(560, 300, 64, 64), spp=16,
                       probes=2000, max_sample=64, full_frame_spp=1),
@@ -54,6 +56,45 @@ def probes(name, wl):
     ys[k] = y0 + np.minimum((u[k, 1] * ch).astype(np.uint32), ch - 1)
     ss = np.minimum((u[:, 2] * c["max_sample"]).astype(np.uint32), c["max_sample"] - 1)
     return xs, ys, ss
+
+
+MATERIAL_ROUTINES = ("reflect", "refract", "scatter", "dielectric")   # rayReflect, rayRefract, rayScatter, rayRefractDielectric
+
+
+def material_vectors(scene, n, stream):
+    """Deterministic inputs of the material routines (raytracer.cl:362-435): n × 16 float32 records
+    {incoming direction (unit, or — every 8th — slightly off unit length like a refracted one), hit point,
+    normal (unit; every 16th the un-normalised (p − c)/r of a grazing sphere hit), colour so far in (0,1],
+    material id bits, s_seed bits (bounce + sample), pixel x bits, pixel y bits}.  Materials cycle over ALL
+    materials of the scene, so every routine also meets types it is normally not called for."""
+    f32 = np.float32
+    u = rt.workloads.uniforms(n, stream, SEED)
+    u2 = rt.workloads.uniforms(n, stream + 1, SEED)
+    u3 = rt.workloads.uniforms(n, stream + 2, SEED)
+
+    def unit(v):
+        ln = np.sqrt((v * v).sum(1, dtype=f32)).astype(f32)
+        ln[ln == 0] = 1
+        return (v / ln[:, None]).astype(f32)
+
+    d = unit((u[:, :3] * f32(2.0) - f32(1.0)).astype(f32))
+    k = np.arange(n) % 8 == 3
+    d[k] = (d[k] * (f32(0.7) + u[k, 3:4] * f32(0.6))).astype(f32)
+    nrm = unit((u2[:, :3] * f32(2.0) - f32(1.0)).astype(f32))
+    k = np.arange(n) % 16 == 5
+    nrm[k] = (nrm[k] * (f32(0.98) + u2[k, 3:4] * f32(0.04))).astype(f32)
+    k = np.arange(n) % 4 == 1                      # grazing incidence: direction nearly perpendicular to the normal
+    d[k] = unit((d[k] - nrm[k] * (d[k] * nrm[k]).sum(1, keepdims=True) * f32(0.999)).astype(f32))
+    p = (u3[:, :3] * f32(20.0) - f32(10.0)).astype(f32)
+    col = np.maximum(u3[:, [3, 0, 1]], f32(1e-3)).astype(f32)
+    rec = np.zeros((n, 16), dtype=f32)
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = d, p, nrm, col
+    words = rec.view(np.uint32)
+    words[:, 12] = np.arange(n) % max(len(scene.materials), 1)
+    words[:, 13] = (u[:, 3] * 600).astype(np.uint32)
+    words[:, 14] = (u2[:, 3] * 3840).astype(np.uint32)
+    words[:, 15] = (u3[:, 2] * 2160).astype(np.uint32)
+    return rec
 
 
 def scene_hash(wl, table):

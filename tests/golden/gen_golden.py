@@ -43,9 +43,14 @@ def gen_case(name, ref, table, threads=8):
                                                              time.time() - t0))
 
 
-def gen_units(ref, n=1000):
+def gen_units(ref, n=2000):
     wl = cases.workload("all_kinds")
+    table = rt.workloads.make_random_table(cases.SEED)
     out = {}
+    # material routines (raytracer.cl:362-435): rayReflect, rayRefract, rayScatter, rayRefractDielectric
+    for i, routine in enumerate(cases.MATERIAL_ROUTINES):
+        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i)
+        out["mat_" + routine] = ref.material(i, wl.scene, table, vec).view(np.uint32)
     for i, kind in enumerate(("sphere", "plane", "lens")):
         rays, prim, _ = cases.unit_rays(kind, wl.scene, n, 100 + 10 * i)
         out[kind] = ref.hit(i, wl.scene, rays, prim).view(np.uint32)
@@ -57,6 +62,9 @@ def gen_units(ref, n=1000):
     out["scene"] = hs.view(np.uint32)
     for k in ("sphere", "plane", "lens", "triangle", "scene"):
         print("unit %-8s hits %d / %d" % (k, int((out[k].view(np.float32)[:, 0] > 0).sum()), n))
+    for routine in cases.MATERIAL_ROUTINES:
+        v = out["mat_" + routine].view(np.float32)
+        print("unit %-10s distinct directions %d / %d" % (routine, len(np.unique(v[:, 3:6], axis=0)), n))
     np.savez_compressed(os.path.join(cases.GOLDEN_DIR, "units.npz"), **out)
 
 

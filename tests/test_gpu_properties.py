@@ -555,7 +555,7 @@ def test_walk_slices_change_no_bit(inside, textured, oracle, table):
 
 
 @pytest.mark.parametrize("inside", [False, True])
-def test_walk_slices_with_several_meshes(inside):
+def test_walk_slices_with_several_meshes(inside, oracle):
     """Two overlapping BVH meshes (dielectric and textured): the state machine walks them one after the
     other per bounce (pt_samples_w<true>) — against the walks in place and against the face scan."""
     s, cam = _mesh_scene(48, 30, inside)
@@ -575,4 +575,18 @@ def test_walk_slices_with_several_meshes(inside):
         for a, b in zip(out[0], out[k]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
     assert (out[0][1][..., :3].sum(-1) > 0).mean() > 0.2
+    # ... and against the oracle: per pixel-sample probes bit for bit, and a 16-sample frame of pt_samples_w<true>
+    # within 1e-4 of the oracle's progressive image
+    t.setOption(t.OPT_WALK_SLICES, 1)
+    t.setOption(t.OPT_ACCEL, 1)
+    table = t.getRandomTable()
+    rng = np.random.RandomState(11)
+    xs, ys, ss = rng.randint(0, w, 1500), rng.randint(0, h, 1500), rng.randint(0, 512, 1500)
+    got = t.traceSamples(cam, xs, ys, ss)
+    exp, _ = oracle.samples(s, cam, table, w, h, xs, ys, ss)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    img = t.renderFrame(cam, 16)
+    ref, _ = oracle.render(s, cam, table, w, h, 2, count=16, threads=16)
+    dev = np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)
+    assert dev.max() <= 1e-4, dev.max()
     t.close()

@@ -72,6 +72,17 @@ def test_unit_intersections_bit_exact(oracle):
     assert np.array_equal(hs[:, 0], exp[:, 0])
 
 
+def test_unit_material_routines_bit_exact(oracle, table):
+    """rayReflect / rayRefract / rayScatter / rayRefractDielectric (raytracer.cl:362-435) of the oracle against the
+    vectors the compiled reference kernel produced (tests/golden/gen_golden.py)."""
+    g = load("units")
+    wl = cases.workload("all_kinds")
+    n = g["mat_reflect"].shape[0]
+    for i, routine in enumerate(cases.MATERIAL_ROUTINES):
+        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i)
+        assert np.array_equal(oracle.material(i, wl.scene, table, vec).view(np.uint32), g["mat_" + routine]), routine
+
+
 def test_random_table_three_implementations_agree(oracle, table):
     """numpy twin (workloads.py) == oracle C == product host function rt_make_random_table."""
     t_oracle = oracle.make_random_table(cases.SEED)

@@ -50,3 +50,21 @@ def test_camera_inside_glass_and_grazing(oracle, ref, table):
         a = ref.progressive(wl.scene, cam, table, 96, 64, 3, threads=4)
         b, _ = oracle.render(wl.scene, cam, table, 96, 64, 2, count=3, threads=4)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_unit_vectors_ten_thousand_per_routine(oracle, ref, table):
+    """10^4 random (ray, primitive) pairs per intersection routine and 10^4 records per material
+    routine, oracle against the compiled reference kernel, bit for bit (fresh streams, not the committed ones)."""
+    wl = cases.workload("all_kinds")
+    n = 10000
+    for i, kind in enumerate(("sphere", "plane", "lens")):
+        rays, prim, _ = cases.unit_rays(kind, wl.scene, n, 300 + 10 * i)
+        assert np.array_equal(oracle.hit(i, wl.scene, rays, prim).view(np.uint32),
+                              ref.hit(i, wl.scene, rays, prim).view(np.uint32)), kind
+    rays, mesh, face = cases.unit_rays("triangle", wl.scene, n, 340)
+    assert np.array_equal(oracle.hit_triangle(wl.scene, rays, mesh, face).view(np.uint32),
+                          ref.hit_triangle(wl.scene, rays, mesh, face).view(np.uint32))
+    for i, routine in enumerate(cases.MATERIAL_ROUTINES):
+        vec = cases.material_vectors(wl.scene, n, 400 + 10 * i)
+        assert np.array_equal(oracle.material(i, wl.scene, table, vec).view(np.uint32),
+                              ref.material(i, wl.scene, table, vec).view(np.uint32)), routine

@@ -15,24 +15,58 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# issue cost in cycles per wave64 instruction per SIMD (profiles/r02_valu_microbench.md, 8 waves/SIMD, wall clock)
-FULL, MOV, HALF, TRANS = 2.0, 3.0, 4.0, 8.0
+# Issue cost in cycles per wave64 instruction per SIMD, measured on MI355X with tools/valu_microbench.hip
+# (profiles/r02_valu_microbench.md; 8 resident waves per SIMD, wall clock × measured shader clock, loop overhead
+# included, rounded to the datapath's granularity): the SIMD is 32 lanes wide, so a full-rate wave64 instruction
+# takes 2 cycles; a second group of opcodes runs at half rate, transcendentals at an eighth of the lanes.
+FULL, HALF, TRANS = 2.0, 4.0, 8.0
+
+
+def counter_group(op):
+    """Which rocprofv3 SQ_INSTS_VALU_* class an opcode is assumed to be counted in ('other' = none of them)."""
+    b = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if re.match(r"v_(rcp|rcp_iflag|rsq|sqrt|exp|log|sin|cos)_f32", b): return "TRANS_F32"
+    if re.match(r"v_(add|sub|subrev)_f32", b): return "ADD_F32"
+    if re.match(r"v_mul_f32", b): return "MUL_F32"
+    if re.match(r"v_(fma|fmac|mac|mad|fmaak|fmamk)_f32", b): return "FMA_F32"
+    if re.match(r"v_(add|mul|fma)_f64", b): return b[2:5].upper() + "_F64"
+    if re.match(r"v_cvt_", b): return "CVT"
+    if re.match(r"v_(lshl_add_u64|mad_u64_u32|mad_i64_i32|lshlrev_b64|lshrrev_b64|ashrrev_i64)", b): return "INT64"
+    if re.match(r"v_(add|sub|subrev|addc|subb|subbrev)(_co)?_[ui]32|v_(and|or|xor|not)_b32|v_(lshlrev|lshrrev|ashrrev)_[bi]32|"
+                r"v_mul_(lo|hi)_[ui]32|v_mul_[ui]32_[ui]24|v_mad_[ui]32_[ui]24|v_(lshl_add|add3|add_lshl|lshl_or|and_or|or3)_[ub]32|"
+                r"v_bfe_|v_bfi_|v_(min|max)3?_[ui]32|v_bcnt|v_mbcnt|v_alignbit", b): return "INT32"
+    return "other"
+
+
+def issue_cost(op):
+    """Measured issue cost of a VALU opcode (cycles per wave-instruction per SIMD)."""
+    b = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if re.match(r"v_(rcp|rcp_iflag|rsq|sqrt|exp|log|sin|cos)_", b): return TRANS
+    if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|fmaak|fmamk)_f32", b): return FULL
+    if re.match(r"v_(add|sub|subrev)(_co)?_u32|v_(and|or|xor|not)_b32", b): return FULL
+    if b.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr")): return 2.5      # 2.48 measured with distinct sources
+    if b.startswith("v_cndmask_b32"): return 2.2                               # v_cmp + v_cndmask pair 6.5, v_cmp alone 4.3
+    return HALF   # f64, packed f32, integer multiply / shifts / 3-operand integer, compares, conversions, min / max,
+                  # floor, v_div_scale / fmas / fixup, lane reads and writes: 4.2–4.4 measured
 
 
 def cost_class(op):
     """→ (class name, cycles) for a VALU opcode; None for non-VALU."""
     if not op.startswith("v_"):
         return None
-    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
-    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_", base):
-        return ("trans", TRANS)
-    if base.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr")):
-        return ("mov", MOV)
-    if re.match(r"v_(add|sub|subrev|mul|fma|fmac|mac|mad|fmaak|fmamk)_f32", base) or \
-       re.match(r"v_(add|sub|subrev|addc|subb|subbrev)(_co)?_u32", base) or re.match(r"v_(and|or|xor|not)_b32", base) or \
-       base.startswith("v_cndmask_b32"):
-        return ("full", FULL)
-    return ("half", HALF)   # f64, packed f32, integer multiply, shifts, compares, conversions, min/max, div helpers, lane reads
+    c = issue_cost(op)
+    return ("trans" if c == TRANS else "half" if c == HALF else "full", c)
+
+
+def group_costs(ops):
+    """Static average issue cost per counter group of one kernel's opcode histogram: {group: (instructions, avg cost)}."""
+    n, cyc = collections.Counter(), collections.Counter()
+    for op, k in ops.items():
+        if op.startswith("v_"):
+            g = counter_group(op)
+            n[g] += k
+            cyc[g] += k * issue_cost(op)
+    return {g: (n[g], cyc[g] / n[g]) for g in n}
 
 
 def device_asm(force=False):

@@ -121,6 +121,25 @@ __device__ __forceinline__ bool lane_on(int mask) {
 #define I_READFIRSTLANE(i) asm volatile("v_readfirstlane_b32 s20, %0" : : "v"(a##i) : "s20");
 #define I_S_NOP(i) asm volatile("s_nop 0");
 #define I_S_ADD(i) asm volatile("s_add_u32 s20, s20, 1" : : : "s20", "scc");
+#define I_CNDMASK_VCC(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(b));   // vcc set before the loop, not clobbered
+#define I_CMP_E64(i) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(a##i), "v"(b) : "s20", "s21");
+#define I_READLANE(i) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(a##i) : "s20");
+#define I_WRITELANE(i) asm volatile("v_writelane_b32 %0, s20, 3" : "+v"(a##i) : : "s20");
+#define I_LSHL_ADD_U64(i) asm volatile("v_lshl_add_u64 %0, %1, 2, %0" : "+v"(d##i) : "v"(db));
+#define I_MAD_U64_U32(i) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %1, %0" : "+v"(d##i) : "v"(ub) : "s20", "s21");
+#define I_LSHL_ADD_U32(i) asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(u##i) : "v"(ub));
+#define I_ADD3_U32(i) asm volatile("v_add3_u32 %0, %1, %1, %0" : "+v"(u##i) : "v"(ub));
+#define I_BFE_U32(i) asm volatile("v_bfe_u32 %0, %1, 3, 5" : "=v"(u##i) : "v"(ub));
+#define I_MIN_F32(i) asm volatile("v_min_f32 %0, %1, %0" : "+v"(a##i) : "v"(b));
+#define I_MIN_U32(i) asm volatile("v_min_u32 %0, %1, %0" : "+v"(u##i) : "v"(ub));
+#define I_MAX3_U32(i) asm volatile("v_max3_u32 %0, %1, %1, %0" : "+v"(u##i) : "v"(ub));
+#define I_MUL_U32_U24(i) asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(u##i) : "v"(ub));
+#define I_SUB_F32(i) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a##i) : "v"(b));
+#define I_XOR_B32(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(u##i) : "v"(ub));
+#define I_MOV_DISTINCT(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a##i) : "v"(u##i));
+#define I_FMAC_F32(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+#define I_CMP_CLASS(i) asm volatile("v_cmp_class_f32 vcc, %0, %1" : : "v"(a##i), "v"(ub) : "vcc");
+#define I_FLOOR_F32(i) asm volatile("v_floor_f32 %0, %1" : "=v"(a##i) : "v"(b));
 // dependent chain: every instruction reads the previous one's result
 #define I_DEP_ADD_F32(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a0) : "v"(b));
 #define I_DEP_MUL_F64(i) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(d0) : "v"(db));
@@ -171,6 +190,25 @@ DEF_KERNEL(dep_rcp_f32, I_DEP_RCP_F32)
 DEF_KERNEL(ieee_div_expr, I_IEEE_DIV)
 DEF_KERNEL(ieee_sqrt_expr, I_IEEE_SQRT)
 DEF_KERNEL(valu_salu_pair, I_VALU_SALU)
+DEF_KERNEL(cndmask_vcc, I_CNDMASK_VCC)
+DEF_KERNEL(cmp_e64, I_CMP_E64)
+DEF_KERNEL(readlane, I_READLANE)
+DEF_KERNEL(writelane, I_WRITELANE)
+DEF_KERNEL(lshl_add_u64, I_LSHL_ADD_U64)
+DEF_KERNEL(mad_u64_u32, I_MAD_U64_U32)
+DEF_KERNEL(lshl_add_u32, I_LSHL_ADD_U32)
+DEF_KERNEL(add3_u32, I_ADD3_U32)
+DEF_KERNEL(bfe_u32, I_BFE_U32)
+DEF_KERNEL(min_f32, I_MIN_F32)
+DEF_KERNEL(min_u32, I_MIN_U32)
+DEF_KERNEL(max3_u32, I_MAX3_U32)
+DEF_KERNEL(mul_u32_u24, I_MUL_U32_U24)
+DEF_KERNEL(sub_f32, I_SUB_F32)
+DEF_KERNEL(xor_b32, I_XOR_B32)
+DEF_KERNEL(mov_distinct, I_MOV_DISTINCT)
+DEF_KERNEL(fmac_f32, I_FMAC_F32)
+DEF_KERNEL(cmp_class, I_CMP_CLASS)
+DEF_KERNEL(floor_f32, I_FLOOR_F32)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_ds_b128_bcast(const float *seed, Out *out, float *sink, int loops, int mask) {
@@ -229,7 +267,7 @@ int main() {
         {"v_cvt_f64_f32", k_cvt_f64_f32, 1}, {"v_cvt_u32_f64", k_cvt_u32_f64, 1}, {"v_cvt_f32_u32", k_cvt_f32_u32, 1},
         {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_add_u32", k_add_u32, 1},
         {"v_and_b32", k_and_b32, 1}, {"v_lshlrev_b32", k_lshl_b32, 1}, {"v_cmp_lt_f32", k_cmp_f32, 1},
-        {"v_cmp+v_cndmask (pair)", k_cmp_cndmask_pair, 2}, {"v_cndmask_b32", k_cndmask, 1},
+        {"v_cmp+v_cndmask (pair)", k_cmp_cndmask_pair, 2},
         {"v_div_scale_f32", k_div_scale, 1}, {"v_div_fmas_f32", k_div_fmas, 1}, {"v_div_fixup_f32", k_div_fixup, 1},
         {"v_pk_mul_f32", k_pk_mul_f32, 1}, {"v_pk_add_f32", k_pk_add_f32, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1},
         {"v_readfirstlane_b32", k_readfirstlane, 1}, {"s_nop 0", k_s_nop, 1}, {"s_add_u32", k_s_add, 1},
@@ -239,6 +277,13 @@ int main() {
         {"IEEE sqrtf (hipcc expansion, per expression)", k_ieee_sqrt_expr, 1},
         {"v_add_f32 + s_add_u32 (pair)", k_valu_salu_pair, 2},
         {"ds_read_b128 broadcast", k_ds_b128_bcast, 1}, {"ds_read_b32 per lane", k_ds_b32, 1},
+        {"v_cndmask_b32 (vcc)", k_cndmask_vcc, 1}, {"v_cmp_lt_f32 e64 (sgpr pair)", k_cmp_e64, 1},
+        {"v_readlane_b32", k_readlane, 1}, {"v_writelane_b32", k_writelane, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1},
+        {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_lshl_add_u32", k_lshl_add_u32, 1}, {"v_add3_u32", k_add3_u32, 1},
+        {"v_bfe_u32", k_bfe_u32, 1}, {"v_min_f32", k_min_f32, 1}, {"v_min_u32", k_min_u32, 1},
+        {"v_max3_u32", k_max3_u32, 1}, {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_sub_f32", k_sub_f32, 1},
+        {"v_xor_b32", k_xor_b32, 1}, {"v_mov_b32 (distinct sources)", k_mov_distinct, 1}, {"v_fmac_f32", k_fmac_f32, 1},
+        {"v_cmp_class_f32", k_cmp_class, 1}, {"v_floor_f32", k_floor_f32, 1},
     };
     const int waves_per_simd[] = {1, 2, 4, 6, 8};
     const int loops = 400;
