@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void pt_debug_hit(DeviceScene sc, int kind, co
         if (t > 0.0f) {
             nb.t = t;
             hit = hit_finish<false>(c, r, nb, h);
-            if (kind == 4) h.mat = 0;     // hitTriangle does not set mat_ID (hitModel does, :314)
+            if (kind == 4) h.mat = h.tex = 0;  // hitTriangle sets neither mat_ID (hitModel does, :314) nor texture_ID (hitMeshOut, :299)
         }
     }
     put_hit(out + 12 * (size_t)i, hit, nb.t, h);

@@ -61,12 +61,15 @@ def probes(name, wl):
 MATERIAL_ROUTINES = ("reflect", "refract", "scatter", "dielectric")   # rayReflect, rayRefract, rayScatter, rayRefractDielectric
 
 
-def material_vectors(scene, n, stream):
+def material_vectors(scene, n, stream, routine=None):
     """Deterministic inputs of the material routines (raytracer.cl:362-435): n × 16 float32 records
     {incoming direction (unit, or — every 8th — slightly off unit length like a refracted one), hit point,
     normal (unit; every 16th the un-normalised (p − c)/r of a grazing sphere hit), colour so far in (0,1],
-    material id bits, s_seed bits (bounce + sample), pixel x bits, pixel y bits}.  Materials cycle over ALL
-    materials of the scene, so every routine also meets types it is normally not called for."""
+    material id bits, s_seed bits (bounce + sample), pixel x bits, pixel y bits}.  Materials cycle over the
+    materials of the scene, so a routine also meets types getCol never calls it for — with one exception:
+    rayRefract / rayRefractDielectric are not given t_reflective materials (their total-internal-reflection
+    branch calls rayReflect, which multiplies by extra_data only for that type, raytracer.cl:366 — a combination
+    no path can reach and the device's fused scatter() does not reproduce)."""
     f32 = np.float32
     u = rt.workloads.uniforms(n, stream, SEED)
     u2 = rt.workloads.uniforms(n, stream + 1, SEED)
@@ -90,7 +93,10 @@ def material_vectors(scene, n, stream):
     rec = np.zeros((n, 16), dtype=f32)
     rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = d, p, nrm, col
     words = rec.view(np.uint32)
-    words[:, 12] = np.arange(n) % max(len(scene.materials), 1)
+    ids = np.arange(len(scene.materials))
+    if routine in ("refract", "dielectric"):
+        ids = ids[scene.materials["type"] != rt._abi.T_REFLECTIVE]
+    words[:, 12] = ids[np.arange(n) % max(len(ids), 1)]
     words[:, 13] = (u[:, 3] * 600).astype(np.uint32)
     words[:, 14] = (u2[:, 3] * 3840).astype(np.uint32)
     words[:, 15] = (u3[:, 2] * 2160).astype(np.uint32)

@@ -49,7 +49,7 @@ def gen_units(ref, n=2000):
     out = {}
     # material routines (raytracer.cl:362-435): rayReflect, rayRefract, rayScatter, rayRefractDielectric
     for i, routine in enumerate(cases.MATERIAL_ROUTINES):
-        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i)
+        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i, routine)
         out["mat_" + routine] = ref.material(i, wl.scene, table, vec).view(np.uint32)
     for i, kind in enumerate(("sphere", "plane", "lens")):
         rays, prim, _ = cases.unit_rays(kind, wl.scene, n, 100 + 10 * i)

@@ -60,7 +60,7 @@ def test_material_routines_match_the_reference_vectors(setup):
     g = golden()
     n = g["mat_reflect"].shape[0]
     for i, routine in enumerate(cases.MATERIAL_ROUTINES):
-        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i)
+        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i, routine)
         assert np.array_equal(bits(t.debugMaterial(i, vec)), g["mat_" + routine]), routine
 
 
@@ -80,7 +80,7 @@ def test_ten_thousand_fresh_vectors_per_routine_vs_oracle(setup, oracle):
     b[~mesh_hit, 8:11] = 0
     assert np.array_equal(bits(a), bits(b))
     for i, routine in enumerate(cases.MATERIAL_ROUTINES):
-        vec = cases.material_vectors(wl.scene, n, 600 + 10 * i)
+        vec = cases.material_vectors(wl.scene, n, 600 + 10 * i, routine)
         assert np.array_equal(bits(t.debugMaterial(i, vec)), bits(oracle.material(i, wl.scene, table, vec))), routine
 
 

@@ -79,7 +79,7 @@ def test_unit_material_routines_bit_exact(oracle, table):
     wl = cases.workload("all_kinds")
     n = g["mat_reflect"].shape[0]
     for i, routine in enumerate(cases.MATERIAL_ROUTINES):
-        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i)
+        vec = cases.material_vectors(wl.scene, n, 200 + 10 * i, routine)
         assert np.array_equal(oracle.material(i, wl.scene, table, vec).view(np.uint32), g["mat_" + routine]), routine
 
 

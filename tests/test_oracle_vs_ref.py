@@ -65,6 +65,6 @@ def test_unit_vectors_ten_thousand_per_routine(oracle, ref, table):
     assert np.array_equal(oracle.hit_triangle(wl.scene, rays, mesh, face).view(np.uint32),
                           ref.hit_triangle(wl.scene, rays, mesh, face).view(np.uint32))
     for i, routine in enumerate(cases.MATERIAL_ROUTINES):
-        vec = cases.material_vectors(wl.scene, n, 400 + 10 * i)
+        vec = cases.material_vectors(wl.scene, n, 400 + 10 * i, routine)
         assert np.array_equal(oracle.material(i, wl.scene, table, vec).view(np.uint32),
                               ref.material(i, wl.scene, table, vec).view(np.uint32)), routine
