@@ -309,6 +309,22 @@ PT_DEV Rnd fetch_rnd(const float *__restrict__ table, V3 dir, uint32_t s_seed, u
     return r;
 }
 
+// The same two reads with the per-sample part of the index sums precomputed (queue kernels): for
+// s_seed = depth + sample,   (s_seed·2683 + gx·3931 + gy·2504)·3 = depth·8049 + bv   and
+// s_seed·2683 + gx·3931 + gy = depth·2683 + bu   in uint32 arithmetic (the sums stay below 2^32, see above).
+PT_DEV uint32_t rnd_base_v(uint32_t sample, uint32_t gx, uint32_t gy) { return (sample * 2683u + gx * 3931u + gy * 2504u) * 3u; }
+PT_DEV uint32_t rnd_base_u(uint32_t sample, uint32_t gx, uint32_t gy) { return sample * 2683u + gx * 3931u + gy; }
+PT_DEV Rnd fetch_rnd_b(const float *__restrict__ table, V3 dir, uint32_t depth, uint32_t bv, uint32_t bu) {
+    uint32_t hsh = dir_hash(dir);
+    uint32_t iv = (hsh + bv + depth * 8049u) % RT_RANDOM_BUFFER_SIZE;
+    uint32_t iu = (hsh + bu + depth * 2683u) % RT_RANDOM_BUFFER_SIZE;
+    const float *t = table + iv;
+    Rnd r;
+    r.v = mk(t[0], t[1], t[2]);
+    r.u = table[3 * RT_RANDOM_BUFFER_SIZE + iu];
+    return r;
+}
+
 // ---- nearest-hit search --------------------------------------------------------
 // id of the winning primitive: kind in the top 2 bits
 enum : uint32_t { K_SPHERE = 0u << 30, K_PLANE = 1u << 30, K_LENS = 2u << 30, K_MESH = 3u << 30, K_MASK = 3u << 30 };
@@ -914,8 +930,11 @@ PT_DEV V3 texture_rgb(const DeviceScene &sc, float s, float t, uint32_t tex_id) 
 // t_textured.  All kinds end in the same tail: new origin = hit point, new
 // direction = v, normalised unless it is a refraction (:386,:428 do not
 // renormalise).
+// set_origin = false: the caller has already moved the ray's origin to the hit point (the queue kernels do so
+// right after the hit search, so that the hit point is not carried in registers of its own).
 template <bool COUNT>
-PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, const Rnd &rnd) {
+PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, const Rnd &rnd,
+                    bool set_origin = true) {
     V3 v;
     bool renorm = true;
     if (type == RT_DIFFUSE || type == RT_TEXTURED) {
@@ -967,7 +986,7 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
     } else {
         return;  // unknown type: the reference's switch has no default (rejected by rt_set_scene)
     }
-    r.o = h.p;
+    if (set_origin) r.o = h.p;
     if (renorm) v = normalize(v);
     r.d = v;
     out = vmin(out, col);  // mixCol is min(), :437

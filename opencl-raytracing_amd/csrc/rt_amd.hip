@@ -302,7 +302,7 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #define PT_Q_WAVES_ACCEL 6  // scenes with a mesh BVH (A/B, 5 / 6 / 7 / 8: C5 at 16 spp 165 / 153 / 148 / 151 ms)
 #endif
 #ifndef PT_Q_WAVES_SPHERE_BVH
-#define PT_Q_WAVES_SPHERE_BVH 5  // scenes whose only BVH is the sphere BVH (C4 at 64 spp: 5 → 772 ms, 6 → 794 ms)
+#define PT_Q_WAVES_SPHERE_BVH 6  // scenes whose only BVH is the sphere BVH (C4 at 8 spp, r02: 5 → 76.9 ms, 6 → 71.8 ms)
 #endif
 #ifndef QUEUE_MIN_SAMPLES
 #define QUEUE_MIN_SAMPLES 384u
@@ -329,7 +329,9 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
 #define PT_Q_BLOCK_WAVES 1  // waves per workgroup of pt_samples_q (they share only the staged materials): a wave that is through frees
                             // its LDS and wave slot at once instead of waiting for three others (A/B on C2: 4 → 2.42 ms, 2 → 2.42, 1 → 2.34)
 #endif
-template <bool COUNT, bool ACCEL, int WAVES>
+// ACCEL: the sphere BVH walk is compiled in; MACCEL: the mesh BVH walk too.  A scene whose only BVH is the sphere
+// BVH (C4) runs <true, false>: without the mesh walk's registers the kernel keeps 6 waves per SIMD.
+template <bool COUNT, bool ACCEL, bool MACCEL, int WAVES>
 __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
@@ -383,16 +385,15 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
     const float inv_count = 1.0f / (float)count;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
-    uint32_t idx = 0, depth = 0, sample = 0, gx = 0, gy = 0;
-    int type = 0;
-    float extra = 0.0f;
-    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);
+    // Per-lane state carried from one iteration to the next, kept small (the kernel sits on its VGPR budget):
+    // the hit POINT is not carried — the ray's origin is moved there as soon as the hit is known — and the
+    // per-sample part of the table index sums is precomputed (bv, bu) instead of carrying sample, x and y.
+    uint32_t idx = 0, depth = 0, bv = 0, bu = 0;
+    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);   // col: material colour or texel of the hit
     Ray r;
     r.o = r.d = mk(0.0f, 0.0f, 0.0f);
-    Hit h;
-    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
-    h.u = h.v = 0.0f;
-    h.tex = h.mat = 0;
+    V3 hn = mk(0.0f, 0.0f, 0.0f);   // normal and material of the hit the next interaction happens at
+    uint32_t hmat = 0;
     Rnd rnd;
     rnd.v = mk(0.0f, 0.0f, 0.0f);
     rnd.u = 0.0f;
@@ -414,11 +415,12 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                 // (idx + 0.5)/count lies >= 0.5/count away from every integer, far more than the rounding
                 // of the float product (idx < 8192, count <= 512)
                 uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);
-                sample = fp.first + (idx - p * count);
+                const uint32_t sample = fp.first + (idx - p * count);
                 float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
                        q4 = rec[5 * p + 4];
-                gx = xy[2 * p];
-                gy = xy[2 * p + 1];
+                const uint32_t gx = xy[2 * p], gy = xy[2 * p + 1];
+                bv = rnd_base_v(sample, gx, gy);
+                bu = rnd_base_u(sample, gx, gy);
                 uint32_t bits = __float_as_uint(q0.w);
                 if (COUNT) cn.c[CN_SAMPLES]++;
                 if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
@@ -426,17 +428,14 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                     slot[3 * idx + 1] = q3.y;
                     slot[3 * idx + 2] = q3.z;
                 } else {
-                    depth = (bits >> 8) & 0xFFu;
-                    type = (int)(bits >> 16);
-                    h.p = xyz(q0);
-                    h.n = xyz(q1);
-                    extra = q1.w;
+                    depth = (bits >> 8) & 0xFFu;   // (type and extra_data of the record are the material's: re-read below)
+                    hn = xyz(q1);
                     r.o = xyz(q0);
                     r.d = xyz(q2);
-                    h.mat = __float_as_uint(q2.w);
+                    hmat = __float_as_uint(q2.w);
                     out = xyz(q3);
                     col = xyz(q4);
-                    if (PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+                    if (PT_RNG_PREFETCH) rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
                     active = true;
                 }
             }
@@ -462,8 +461,18 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 #endif
         // ---- one material interaction for every active lane
         if (active) {
-            if (!PT_RNG_PREFETCH) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
-            scatter<COUNT>(c, r, out, h, type, extra, col, rnd);
+            if (!PT_RNG_PREFETCH) rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
+            Hit at;   // the vertex this interaction happens at: the ray's origin already stands on it
+            at.p = r.o;
+            at.n = hn;
+            at.u = at.v = 0.0f;
+            at.tex = 0;
+            at.mat = hmat;
+            int type;
+            float extra;
+            V3 mcol;
+            load_material(c, hmat, type, extra, mcol);   // type and extra_data are not carried: one LDS read each
+            scatter<COUNT>(c, r, out, at, type, extra, col, rnd, false);
             depth++;
             if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
                 slot[3 * idx] = out.x;
@@ -476,14 +485,23 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
         // ---- nearest hit for every lane still active; the table reads of the NEXT material
         // interaction are issued first (they depend on the ray direction only)
         if (active) {
-            if (PT_RNG_PREFETCH == 1) rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+            if (PT_RNG_PREFETCH == 1) rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
             V3 res;
             bool done = false;
-            if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
+            Hit h;
+            h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+            h.u = h.v = 0.0f;
+            h.tex = h.mat = 0;
+            Nearest nb;
+            hit_primitives<COUNT, ACCEL>(c, r, nb);
+            hit_models<COUNT, MACCEL>(c, r, nb);
+            if (!hit_finish<COUNT>(c, r, nb, h)) {
                 res = mk(0.0f, 0.0f, 0.0f);
                 done = true;
             } else {
                 if (COUNT) cn.c[CN_H_BOUNCE]++;
+                int type;
+                float extra;
                 load_material(c, h.mat, type, extra, col);
                 if (type == RT_LIGHT) {
                     res = vmin(out, col);
@@ -500,7 +518,12 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                 active = false;
             } else if (PT_RNG_PREFETCH == 2) {
                 // this lane WILL interact next iteration: its table reads fly during the refill step
-                rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
+                rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
+            }
+            if (!done) {   // the next interaction happens here
+                r.o = h.p;
+                hn = h.n;
+                hmat = h.mat;
             }
         }
         PT_STAMP(c, 4);
@@ -591,16 +614,12 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     int phase = 0;
-    uint32_t idx = 0, depth = 0, sample = 0, gx = 0, gy = 0;
-    int type = 0;
-    float extra = 0.0f;
-    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);
+    uint32_t idx = 0, depth = 0, bv = 0, bu = 0;   // (see pt_samples_q: hit point and sample / pixel are not carried)
+    V3 col = mk(0.0f, 0.0f, 0.0f), out = mk(0.0f, 0.0f, 0.0f);   // col: material colour or texel of the hit
     Ray r;
     r.o = r.d = mk(0.0f, 0.0f, 0.0f);
-    Hit h;
-    h.p = h.n = mk(0.0f, 0.0f, 0.0f);
-    h.u = h.v = 0.0f;
-    h.tex = h.mat = 0;
+    V3 hn = mk(0.0f, 0.0f, 0.0f);
+    uint32_t hmat = 0;
     float nb_t = RT_MAX_DISTANCE;       // nearest sphere / plane / lens of the current bounce
     uint32_t nb_id = PT_NO_HIT;
     uint32_t wcur = 0, wbest = 0;       // the walk's position and its best face so far
@@ -621,25 +640,23 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
             if (need && cand < total) {
                 idx = cand;
                 uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);  // = idx / count exactly (pt_samples_q)
-                sample = fp.first + (idx - p * count);
+                const uint32_t sample = fp.first + (idx - p * count);
                 float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
                        q4 = rec[5 * p + 4];
-                gx = xy[2 * p];
-                gy = xy[2 * p + 1];
+                const uint32_t gx = xy[2 * p], gy = xy[2 * p + 1];
+                bv = rnd_base_v(sample, gx, gy);
+                bu = rnd_base_u(sample, gx, gy);
                 uint32_t bits = __float_as_uint(q0.w);
                 if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
                     slot[3 * idx] = q3.x;
                     slot[3 * idx + 1] = q3.y;
                     slot[3 * idx + 2] = q3.z;
                 } else {
-                    depth = (bits >> 8) & 0xFFu;
-                    type = (int)(bits >> 16);
-                    h.p = xyz(q0);
-                    h.n = xyz(q1);
-                    extra = q1.w;
+                    depth = (bits >> 8) & 0xFFu;   // (type and extra_data of the record are the material's: re-read below)
+                    hn = xyz(q1);
                     r.o = xyz(q0);
                     r.d = xyz(q2);
-                    h.mat = __float_as_uint(q2.w);
+                    hmat = __float_as_uint(q2.w);
                     out = xyz(q3);
                     col = xyz(q4);
                     active = true;
@@ -654,8 +671,18 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
         }
         // ---- state 0: one material interaction, then the primitives that are not models
         if (active && phase == 0) {
-            Rnd rnd = fetch_rnd(sc.table, r.d, depth + sample, gx, gy);
-            scatter<false>(c, r, out, h, type, extra, col, rnd);
+            Rnd rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
+            Hit at;
+            at.p = r.o;
+            at.n = hn;
+            at.u = at.v = 0.0f;
+            at.tex = 0;
+            at.mat = hmat;
+            int type;
+            float extra;
+            V3 mcol;
+            load_material(c, hmat, type, extra, mcol);
+            scatter<false>(c, r, out, at, type, extra, col, rnd, false);
             depth++;
             if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
                 slot[3 * idx] = out.x;
@@ -735,10 +762,16 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
             }
             V3 res;
             bool done = false;
+            Hit h;
+            h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+            h.u = h.v = 0.0f;
+            h.tex = h.mat = 0;
             if (!hit_finish<false>(c, r, nb, h)) {
                 res = mk(0.0f, 0.0f, 0.0f);
                 done = true;
             } else {
+                int type;
+                float extra;
                 load_material(c, h.mat, type, extra, col);
                 if (type == RT_LIGHT) {
                     res = vmin(out, col);
@@ -753,6 +786,10 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
                 slot[3 * idx + 1] = res.y;
                 slot[3 * idx + 2] = res.z;
                 active = false;
+            } else {   // the next interaction happens here
+                r.o = h.p;
+                hn = h.n;
+                hmat = h.mat;
             }
         }
     }
@@ -1450,13 +1487,13 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         size_t lds_q = static_f4 * sizeof(float4) + PT_Q_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
-#define PT_CALL_QUEUE_W(C, A, W) \
-    hipLaunchKernelGGL((pt_samples_q<C, A, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
-#define PT_CALL_QUEUE(C, A)                                                            \
-    do {                                                                               \
-        if (!(A)) PT_CALL_QUEUE_W(C, false, PT_Q_WAVES);                               \
-        else if (sphere_bvh_only) PT_CALL_QUEUE_W(C, true, PT_Q_WAVES_SPHERE_BVH);     \
-        else PT_CALL_QUEUE_W(C, true, PT_Q_WAVES_ACCEL);                               \
+#define PT_CALL_QUEUE_W(C, A, M, W) \
+    hipLaunchKernelGGL((pt_samples_q<C, A, M, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+#define PT_CALL_QUEUE(C, A)                                                                  \
+    do {                                                                                     \
+        if (!(A)) PT_CALL_QUEUE_W(C, false, false, PT_Q_WAVES);                              \
+        else if (sphere_bvh_only) PT_CALL_QUEUE_W(C, true, false, PT_Q_WAVES_SPHERE_BVH);    \
+        else PT_CALL_QUEUE_W(C, true, true, PT_Q_WAVES_ACCEL);                               \
     } while (0)
 #define PT_CALL_FIXED(C, A) \
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)

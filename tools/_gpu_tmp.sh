@@ -1,5 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python3 tools/ref_distance.py --hsaco default --out gpurun_out/ref_distance_default.json > /dev/null 2> gpurun_out/ref_distance_default.err || { tail -5 gpurun_out/ref_distance_default.err; exit 1; }
-timeout -k 10 400 python3 tools/ref_distance.py --hsaco nocontract --out gpurun_out/ref_distance_nocontract.json > /dev/null 2> gpurun_out/ref_distance_nocontract.err || { tail -5 gpurun_out/ref_distance_nocontract.err; exit 1; }
-echo ok
+timeout -k 10 200 python3 tools/quick_bench.py c2:64 c3:256 c4:8 c4:64 c5:16:960:540 2>/dev/null || exit 1
+timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu --deselect tests/test_gpu_bench.py 2>&1 | tail -4
