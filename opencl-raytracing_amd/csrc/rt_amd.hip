@@ -567,8 +567,11 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 #ifndef PT_W_WAVES
 #define PT_W_WAVES 5  // A/B on C5 at 16 spp: 4 → 116.5 ms, 5 → 110.2, 6 → 116.1
 #endif
+#ifndef PT_W_BLOCK_WAVES
+#define PT_W_BLOCK_WAVES 1  // waves per workgroup (see PT_Q_BLOCK_WAVES)
+#endif
 template <bool MULTI>
-__global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, uint32_t pixels_per_wave,
@@ -578,14 +581,18 @@ __global__ __launch_bounds__(256, PT_W_WAVES) void pt_samples_w(DeviceScene sc, 
     Ctx c{sc, stage_materials(sc, s_mat), nullptr};
     c.lwin = staged_winners(sc, s_mat);
     c.lpln = staged_planes(sc, s_mat);
+#if PT_W_BLOCK_WAVES == 1
+    const uint32_t wave = 0u, lane = threadIdx.x;
+#else
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+#endif
     char *wave_lds = reinterpret_cast<char *>(s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
     float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
     uint32_t pix0 = 0;
-    const uint32_t npix = live_take(fp, live_count, blockIdx.x * 4u + wave, pixels_per_wave, pix0);
+    const uint32_t npix = live_take(fp, live_count, blockIdx.x * (uint32_t)PT_W_BLOCK_WAVES + wave, pixels_per_wave, pix0);
     const uint32_t count = fp.count, total = npix * count;
     const float4 *rec = s_rec;
     const uint32_t *xy = s_xy;
@@ -1502,14 +1509,14 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // (the last slot range's; one range is the normal case)
         if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
             // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
-            uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4);
-            size_t lds_w = static_f4 * sizeof(float4) + 4 * (size_t)queue_wave_lds_bytes(ppw_w, count);
-            dim3 gridw((units_for(ppw_w) + 3) / 4);
+            uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4, PT_W_BLOCK_WAVES);
+            size_t lds_w = static_f4 * sizeof(float4) + PT_W_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw_w, count);
+            dim3 gridw((units_for(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
             if (ctx->walk_jobs.n == 1)
-                hipLaunchKernelGGL(pt_samples_w<false>, gridw, block, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
+                hipLaunchKernelGGL(pt_samples_w<false>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
                                    ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u);
             else
-                hipLaunchKernelGGL(pt_samples_w<true>, gridw, block, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
+                hipLaunchKernelGGL(pt_samples_w<true>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
                                    ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n);
         } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
