@@ -405,11 +405,13 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 //   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
 template <bool COUNT>
 PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, uint32_t &best_id, LaneCounters *cn) {
+    // per-ray constants of the culling tests: hardware rcp / sqrt (1 ulp) scaled to the safe side — the margins
+    // below carry 2 % (k_ray) and 1e-5 relative (slab test) of slack, the sphere tests themselves stay IEEE
     float dd = dot(r.d, r.d);
-    float c_ray = 2.0e-6f + 2.0f * fabsf(dd - 1.0f) / fminf(dd, 1.0f);
-    float k_ray = sqrtf(2.0f * c_ray) * 1.02f;   // margin per unit of distance to the node
+    float c_ray = 2.0e-6f + 2.0f * fabsf(dd - 1.0f) * (__builtin_amdgcn_rcpf(fminf(dd, 1.0f)) * 1.000002f);
+    float k_ray = __builtin_amdgcn_sqrtf(2.0f * c_ray) * 1.02f;   // margin per unit of distance to the node
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
-    V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    V3 inv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
     // which child is nearer along each axis: bit k set → the RIGHT child (higher coordinates) first
     uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 

@@ -75,10 +75,13 @@ template <int MODE>
 PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &cur, int &state,
                            uint32_t &best_face, float &ft, float &fu, float &fv, uint32_t max_steps, uint32_t &hits,
                            LaneCounters *dbg = nullptr) {
-    float dlen = sqrtf(dot(r.d, r.d));
-    float inv_len = 1.0f / dlen;
+    // Per-ray constants of the CULLING tests only (never of a face test): hardware sqrt / rcp (1 ulp) instead of the
+    // correctly rounded expansions (54 / 43 issue cycles each, profiles/r02_valu_microbench.md) — every use below
+    // carries a relative slack of 1e-5 or more, and dlen is rounded UP by 2^-20 where a larger value is the safe side.
+    float dlen = __builtin_amdgcn_sqrtf(dot(r.d, r.d)) * 1.000001f;
+    float inv_len = __builtin_amdgcn_rcpf(dlen);
     V3 dh = r.d * inv_len;
-    V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    V3 inv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
     uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
@@ -139,7 +142,8 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                 float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
                 float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;
                 float reach = dfar + 2.0f * ex.z;
-                float m_steep = steep ? PT_MESH_K * reach / (ex.w * cosmin) : INFINITY;
+                // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
+                float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
                 float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
                 float m = fminf(m_steep, m_cap) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
                 float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
@@ -158,12 +162,13 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                     // own extent along x by at most eta_total * (that extent).  Along n' = the part of the
                     // cone axis perpendicular to d every face of the subtree is thin: an edge e is
                     // perpendicular to its normal, so |e . n'| <= |e| (sin alpha + |cos psi|) / sin psi.
-                    V3 np = (xyz(cn) - dh * x) * (1.0f / sb);   // |x| <= sin(alpha) + tau here
+                    V3 np = (xyz(cn) - dh * x) * __builtin_amdgcn_rcpf(sb);   // |x| <= sin(alpha) + tau here (sb > 0.5)
                     float hx = 0.5f * (b.x - a.x), hy = 0.5f * (b.y - a.y), hz = 0.5f * (b.z - a.z);
                     float rn = fabsf(np.x) * hx + fabsf(np.y) * hy + fabsf(np.z) * hz;
                     float dist = (r.o.x - 0.5f * (a.x + b.x)) * np.x + (r.o.y - 0.5f * (a.y + b.y)) * np.y +
                                  (r.o.z - 0.5f * (a.z + b.z)) * np.z;
-                    float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) / sb + 1.0e-5f * (dfar + o_max) + 1.0e-5f;
+                    float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) * (__builtin_amdgcn_rcpf(sb) * 1.000002f) +
+                               1.0e-5f * (dfar + o_max) + 1.0e-5f;
                     if (fabsf(dist) > rn * 1.0001f + mn) miss = true;
                 }
             }
