@@ -50,9 +50,9 @@ WORKLOAD_DESC = {
     "c5": "C5 50k-triangle dielectric mesh",
 }
 # dominant kernel of one fused trace call, per workload (what `roofline` prices), and its first stage
-KERNELS = {"c2": ("pt_samples_q<false, false, false", "pt_prefix<false, false>"),
-           "c3": ("pt_samples_q<false, false, false", "pt_prefix<false, false>"),
-           "c4": ("pt_samples_q<false, true, false", "pt_prefix<false, true>"),
+KERNELS = {"c2": ("pt_samples_q<false, false, 0", "pt_prefix<false, false>"),
+           "c3": ("pt_samples_q<false, false, 1", "pt_prefix<false, false>"),
+           "c4": ("pt_samples_q<false, true, 0", "pt_prefix<false, true>"),
            "c5": ("pt_samples_w<false>", "pt_prefix<false, true>")}
 CROP = {"c2": (900, 330, 32, 16), "c3": (930, 300, 32, 16), "c4": (960, 270, 8, 4), "c5": (1900, 900, 4, 2)}
 

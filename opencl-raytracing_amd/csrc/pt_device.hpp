@@ -157,6 +157,7 @@ struct DeviceScene {
     const float *table;  // 400 000 floats
     const float4 *tex;   // layers × h × w texels
     int tex_w, tex_h, tex_layers;
+    float tex_wf, tex_hf;  // (float)tex_w, (float)tex_h: scalar operands of the sampler (converted per lane they end up hoisted into VGPRs)
     uint32_t material_count, sphere_count, sphere_batches, plane_count, lens_count, model_count;
     // per-face records of all meshes, 3 float4 each: (A.xyz, e1.x), (e1.yz, e2.xy), (e2.z, n.xyz) with
     // e1 = B−A, e2 = C−A, n = normalize(cross(e1,e2)) computed once at upload with the same binary32
@@ -609,7 +610,8 @@ struct Nearest {
     uint32_t face = 0, mat = 0;
     float u = 0.0f, v = 0.0f;
 };
-template <bool COUNT, bool ACCEL>
+// LENSES = false compiles the lens loop out (kernels specialised for scenes of spheres and planes only)
+template <bool COUNT, bool ACCEL, bool LENSES = true>
 PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
     const DeviceScene &sc = c.sc;
     float best_t = nb.t;
@@ -720,7 +722,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
             best_id = K_PLANE | i;
         }
     }
-    for (uint32_t i = 0; i < sc.lens_count; i++) {
+    for (uint32_t i = 0; LENSES && i < sc.lens_count; i++) {
         int which;
         float t = lens_t(r, sc.lenses[i], &which);
         if (t > 0.0f && t < best_t) {
@@ -815,7 +817,8 @@ PT_DEV void hit_models(const Ctx &c, const Ray &r, Nearest &nb) {
     nb.v = best_v;
 }
 
-template <bool COUNT>
+// SIMPLE = true: the winner can only be a sphere or a plane (no lens / mesh code)
+template <bool COUNT, bool SIMPLE = false>
 PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) {
     const DeviceScene &sc = c.sc;
     const float best_t = nb.t;
@@ -848,7 +851,7 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
             hit.mat = p.mat_ID;
         }
         hit.n = neg(n) * sign1(dot(r.d, n));  // :187
-    } else if (kind == K_MESH) {
+    } else if (!SIMPLE && kind == K_MESH) {
         const rt_mesh &mesh = sc.meshes[idx];
         const uint32_t *ib = sc.indices + mesh.index_anchor + 3u * best_face;
         uint32_t ia = mesh.vertex_anchor + ib[0], ibx = mesh.vertex_anchor + ib[1], ic = mesh.vertex_anchor + ib[2];
@@ -864,7 +867,7 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
         // sphere and lens share normal = (p - centre) / radius (:160, :248)
         V3 centre;
         float rad;
-        if (kind == K_SPHERE) {
+        if (SIMPLE || kind == K_SPHERE) {
             if (c.lwin) {
                 float4 w = c.lwin[2 * idx];
                 centre = xyz(w);
@@ -909,7 +912,7 @@ PT_DEV V3 texture_rgb(const DeviceScene &sc, float s, float t, uint32_t tex_id) 
     if (sc.tex_layers <= 0) return mk(0.0f, 0.0f, 0.0f);
     int W = sc.tex_w, H = sc.tex_h;
     int layer = tex_id < (uint32_t)sc.tex_layers ? (int)tex_id : 0;
-    float u = s * (float)W - 0.5f, v = t * (float)H - 0.5f;
+    float u = s * sc.tex_wf - 0.5f, v = t * sc.tex_hf - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     float a = u - fu, b = v - fv;
     int i0 = (fu >= -1.0f && fu <= 1.0e9f) ? (int)fu : 0;

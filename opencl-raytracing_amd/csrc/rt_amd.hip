@@ -35,6 +35,7 @@ struct FrameParams {
     uint32_t first, count;          // samples first .. first+count-1
     uint32_t group_log2;            // lanes per pixel = 1 << group_log2 (<= 64)
     uint32_t seg_cap;               // live list: entries per segment (see LIVE_SEGMENTS)
+    float inv_count;                // 1 / count, the IEEE quotient computed on the host: a scalar operand of the queue kernels
 };
 
 // The live list (pixels that need per-sample work) can be kept in LIVE_SEGMENTS independent segments, workgroup b
@@ -299,7 +300,7 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #define PT_Q_WAVES 6  // waves per SIMD the register allocator must leave room for: 6 = 80 VGPRs (A/B on C2: 5 → 2.62 ms, 6 → 2.48)
 #endif
 #ifndef PT_Q_WAVES_ACCEL
-#define PT_Q_WAVES_ACCEL 6  // scenes with a mesh BVH (A/B, 5 / 6 / 7 / 8: C5 at 16 spp 165 / 153 / 148 / 151 ms)
+#define PT_Q_WAVES_ACCEL 5  // scenes that mix BVH meshes with small ones (every other mesh scene runs pt_samples_w): 96 VGPRs, 2 spilled (6: 22 spilled)
 #endif
 #ifndef PT_Q_WAVES_SPHERE_BVH
 #define PT_Q_WAVES_SPHERE_BVH 6  // scenes whose only BVH is the sphere BVH (C4 at 8 spp, r02: 5 → 76.9 ms, 6 → 71.8 ms)
@@ -329,9 +330,11 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
 #define PT_Q_BLOCK_WAVES 1  // waves per workgroup of pt_samples_q (they share only the staged materials): a wave that is through frees
                             // its LDS and wave slot at once instead of waiting for three others (A/B on C2: 4 → 2.42 ms, 2 → 2.42, 1 → 2.34)
 #endif
-// ACCEL: the sphere BVH walk is compiled in; MACCEL: the mesh BVH walk too.  A scene whose only BVH is the sphere
-// BVH (C4) runs <true, false>: without the mesh walk's registers the kernel keeps 6 waves per SIMD.
-template <bool COUNT, bool ACCEL, bool MACCEL, int WAVES>
+// ACCEL: the sphere BVH walk is compiled in.  GEOM: 0 = the scene holds spheres and planes only (C1, C2, C4: no
+// lens, model or mesh code at all), 1 = everything by brute force or through the sphere BVH, 2 = the mesh BVH
+// walk too.  A scene whose only BVH is the sphere BVH (C4) runs <true, 0>: without the mesh walk's registers the
+// kernel keeps 6 waves per SIMD.
+template <bool COUNT, bool ACCEL, int GEOM, int WAVES>
 __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const float inv_count = 1.0f / (float)count;
+    const float inv_count = fp.inv_count;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     // Per-lane state carried from one iteration to the next, kept small (the kernel sits on its VGPR budget):
@@ -493,9 +496,9 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
             h.u = h.v = 0.0f;
             h.tex = h.mat = 0;
             Nearest nb;
-            hit_primitives<COUNT, ACCEL>(c, r, nb);
-            hit_models<COUNT, MACCEL>(c, r, nb);
-            if (!hit_finish<COUNT>(c, r, nb, h)) {
+            hit_primitives<COUNT, ACCEL, GEOM != 0>(c, r, nb);
+            if (GEOM != 0) hit_models<COUNT, GEOM == 2>(c, r, nb);
+            if (!hit_finish<COUNT, GEOM == 0>(c, r, nb, h)) {
                 res = mk(0.0f, 0.0f, 0.0f);
                 done = true;
             } else {
@@ -570,8 +573,11 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 #ifndef PT_W_BLOCK_WAVES
 #define PT_W_BLOCK_WAVES 1  // waves per workgroup (see PT_Q_BLOCK_WAVES)
 #endif
+#ifndef PT_W_WAVES_MULTI
+#define PT_W_WAVES_MULTI 4  // several meshes: the running minimum over the jobs needs 13 more VGPRs — 109, no scratch at 4 waves per SIMD
+#endif
 template <bool MULTI>
-__global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
+__global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : PT_W_WAVES) void pt_samples_w(DeviceScene sc, FrameParams fp, const PixelRec *__restrict__ recs,
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, uint32_t pixels_per_wave,
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, PT_W_WAVES) void pt_samples_
     const uint32_t faces0 = sc.meshes[mesh0].face_count;
     const uint32_t root0 = sc.mesh_bvh_root[mesh0];
 
-    const float inv_count = 1.0f / (float)count;
+    const float inv_count = fp.inv_count;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     int phase = 0;
@@ -1351,6 +1357,8 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.tex_w = ctx->tex_w;
     s.tex_h = ctx->tex_h;
     s.tex_layers = ctx->tex_layers;
+    s.tex_wf = (float)ctx->tex_w;
+    s.tex_hf = (float)ctx->tex_h;
     s.sphere_count = (uint32_t)ctx->spheres.n;
     s.plane_count = (uint32_t)ctx->planes.n;
     s.lens_count = (uint32_t)ctx->lenses.n;
@@ -1393,6 +1401,11 @@ FrameParams frame_params(const rt_context *ctx, const float cam[12], uint32_t fi
     fp.count = count;
     fp.group_log2 = glog2;
     fp.seg_cap = 0;
+    {
+        volatile float c = (float)count;
+        volatile float q = 1.0f / c;
+        fp.inv_count = count ? q : 0.0f;
+    }
     return fp;
 }
 
@@ -1487,6 +1500,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         uint32_t static_f4 = lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
         const bool sphere_bvh_only = sc.bvh_node_count != 0 && sc.mesh_bvh_root == nullptr;
+        const bool simple_geom = sc.lens_count == 0 && sc.model_count == 0;   // spheres and planes only
         const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
         uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
         dim3 gridq((units_for(ppw) + PT_Q_BLOCK_WAVES - 1) / PT_Q_BLOCK_WAVES), blockq(64 * PT_Q_BLOCK_WAVES);
@@ -1494,13 +1508,13 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         size_t lds_q = static_f4 * sizeof(float4) + PT_Q_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
-#define PT_CALL_QUEUE_W(C, A, M, W) \
-    hipLaunchKernelGGL((pt_samples_q<C, A, M, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
-#define PT_CALL_QUEUE(C, A)                                                                  \
-    do {                                                                                     \
-        if (!(A)) PT_CALL_QUEUE_W(C, false, false, PT_Q_WAVES);                              \
-        else if (sphere_bvh_only) PT_CALL_QUEUE_W(C, true, false, PT_Q_WAVES_SPHERE_BVH);    \
-        else PT_CALL_QUEUE_W(C, true, true, PT_Q_WAVES_ACCEL);                               \
+#define PT_CALL_QUEUE_W(C, A, G, W) \
+    hipLaunchKernelGGL((pt_samples_q<C, A, G, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+#define PT_CALL_QUEUE(C, A)                                                                       \
+    do {                                                                                          \
+        if (!(A)) { if (simple_geom) PT_CALL_QUEUE_W(C, false, 0, PT_Q_WAVES); else PT_CALL_QUEUE_W(C, false, 1, PT_Q_WAVES); } \
+        else if (sphere_bvh_only) { if (simple_geom) PT_CALL_QUEUE_W(C, true, 0, PT_Q_WAVES_SPHERE_BVH); else PT_CALL_QUEUE_W(C, true, 1, PT_Q_WAVES_SPHERE_BVH); } \
+        else PT_CALL_QUEUE_W(C, true, 2, PT_Q_WAVES_ACCEL);                                       \
     } while (0)
 #define PT_CALL_FIXED(C, A) \
     hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
@@ -1509,7 +1523,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // (the last slot range's; one range is the normal case)
         if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
             // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
-            uint32_t ppw_w = queue_pixels_per_wave(count, PT_W_WAVES, static_f4, PT_W_BLOCK_WAVES);
+            uint32_t ppw_w = queue_pixels_per_wave(count, ctx->walk_jobs.n == 1 ? PT_W_WAVES : PT_W_WAVES_MULTI, static_f4, PT_W_BLOCK_WAVES);
             size_t lds_w = static_f4 * sizeof(float4) + PT_W_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw_w, count);
             dim3 gridw((units_for(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
             if (ctx->walk_jobs.n == 1)

@@ -6,8 +6,10 @@ this module; the product package never does.
   Oracle()     liboracle.so — the CPU restatement (pt_oracle.c), always available
                after `make -C oracle` / __graft_entry__.build().
   Reference()  _ref/libref.so — the unmodified reference kernel compiled for
-               x86-64 (build container only; absent on the GPU box unless the
-               prebuilt file travelled).
+               x86-64 and linked with the IEEE-plain builtin stand-ins of
+               ref_shim.cpp (build container only: .gpurunignore keeps it off the
+               GPU box).  "Parity unpinned" in the sense of the build rules — see
+               the header of pt_oracle.c.
   ReferenceGfx950()  _ref_gfx950/ — the same kernel file built for gfx950 with ROCm's REAL OpenCL
                builtin library and run on the GPU through the HIP module API (GPU box only;
                measurement tool of DESIGN.md §3, no pass/fail parity test depends on it).

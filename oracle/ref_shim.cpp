@@ -7,11 +7,17 @@
 // `trace`, `retrace`, `createScene`, `getCol`, `genInitRay`, `hitSphere`,
 // `hitPlane`, `hitLens`, `hitTriangle`, `hitScene`, ... (raytracer.cl:129-558).
 //
-// No OpenCL device exists in the build container, so the definitions below ARE
-// the normative arithmetic of the builtins: every one is the
-// plain IEEE-754 single-precision formula of the OpenCL 1.2 specification,
-// evaluated in a fixed order, with no fused multiply-add.  The C restatement
-// (oracle/pt_oracle.c) and the HIP kernels use exactly the same formulas.
+// No OpenCL device exists in the build container, so the definitions below are
+// STAND-INS written for this build: every one is the plain IEEE-754
+// single-precision formula of the OpenCL 1.2 specification, evaluated in a fixed
+// order, with no fused multiply-add.  The C restatement (oracle/pt_oracle.c) and
+// the HIP kernels use exactly the same formulas — that is the arithmetic contract
+// of this build — but it is ONE legal choice, not THE reference's:
+// a real OpenCL library is free to fuse, to use rsq / rcp, and ROCm's does
+// (profiles/r02_ref_gfx950_builtins.md).  Because of these stand-ins, oracle/_ref
+// pins the oracle to "reference source + IEEE-plain builtins" only; by the build
+// rules that counts as PARITY UNPINNED (oracle/pt_oracle.c header).
+// The library stays in the build container (.gpurunignore).
 //
 // Built with ROCm's clang++ for x86-64 (same compiler as the .cl object, so the
 // ext_vector_type calling convention matches), -O2 -ffp-contract=off.
