@@ -74,10 +74,16 @@
 // The walk is stackless, so (cur, state) is its whole position: mesh_bvh_steps advances it by at most
 // max_steps node visits and returns true once the tree is exhausted — a kernel can interleave walks of
 // different lengths with other work (pt_samples_w).  Start with cur = root, state = 0.
+#ifdef PT_WSTAT  // diagnostic build (tools/wstat.py): wave-level lane census of the walk, never timed
+struct WalkStat { unsigned long long steps, node_lanes, hop_lanes, leaf_runs, leaf_lanes, idle_lanes; };
+#define PT_WSTAT_ARG , WalkStat *ws = nullptr
+#else
+#define PT_WSTAT_ARG
+#endif
 template <int MODE>
 PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &cur, int &state,
                            uint32_t &best_face, float &ft, float &fu, float &fv, uint32_t max_steps, uint32_t &hits,
-                           LaneCounters *dbg = nullptr) {
+                           LaneCounters *dbg = nullptr PT_WSTAT_ARG) {
     // Per-ray constants of the CULLING tests only (never of a face test): hardware sqrt / rcp (1 ulp) instead of the
     // correctly rounded expansions (54 / 43 issue cycles each, profiles/r02_valu_microbench.md) — every use below
     // carries a relative slack of 1e-5 or more, and dlen is rounded UP by 2^-20 where a larger value is the safe side.
@@ -115,6 +121,14 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                     }
                 }
             }
+#ifdef PT_WSTAT
+        if (ws) {
+            ws->steps++;
+            ws->hop_lanes += __popcll(__ballot(!finished && state == FROM_CHILD));
+            ws->node_lanes += __popcll(__ballot(!finished && state < FROM_CHILD));
+            ws->idle_lanes += __popcll(__ballot(finished));
+        }
+#endif
         if (!finished && state < FROM_CHILD) {
         const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
         float4 a = nd[0], b = nd[1];
@@ -202,6 +216,9 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
         const bool flush = (guard & (PT_MESH_LEAF_EVERY - 1u)) == PT_MESH_LEAF_EVERY - 1u || guard + 1u == max_steps ||
                            __all(finished || parked);
         if (flush && __any(parked)) {
+#ifdef PT_WSTAT
+            if (ws) { ws->leaf_runs++; ws->leaf_lanes += __popcll(__ballot(parked)); }
+#endif
             if (parked) {
                 const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
                 uint32_t A = __float_as_uint(nd[0].w), B = __float_as_uint(nd[1].w);

@@ -581,7 +581,11 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                                                     const uint32_t *__restrict__ live,
                                                     const uint32_t *__restrict__ live_count,
                                                     float4 *__restrict__ accum, uint32_t pixels_per_wave,
-                                                    const uint2 *__restrict__ jobs, uint32_t n_jobs) {
+                                                    const uint2 *__restrict__ jobs, uint32_t n_jobs
+#ifdef PT_WSTAT
+                                                    , unsigned long long *wstat
+#endif
+                                                    ) {
     extern __shared__ float4 s_dyn[];
     float4 *s_mat = s_dyn;
     Ctx c{sc, stage_materials(sc, s_mat), nullptr};
@@ -642,6 +646,10 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     uint32_t nb_face = 0, nb_mat = 0;
     float nb_u = 0.0f, nb_v = 0.0f;
 
+#ifdef PT_WSTAT
+    WalkStat ws = {0, 0, 0, 0, 0, 0};
+    unsigned long long it_n = 0, it_active = 0, it_p0 = 0, it_p1 = 0, it_p2 = 0, it_walk_calls = 0;
+#endif
     // every iteration takes samples off the queue, or moves every active lane on (a bounce, or up to
     // PT_WALK_STEPS nodes of a walk that visits each of the < 2^28 nodes at most 3 times)
     for (unsigned long long guard = ((unsigned long long)total + 1ull) * (RT_DEPTH + 2ull) * (3ull * (1ull << 28) / PT_WALK_STEPS + 4ull); guard; guard--) {
@@ -682,6 +690,13 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
             if (next >= total) break;
             continue;
         }
+#ifdef PT_WSTAT
+        it_n++;
+        it_active += __popcll(__ballot(active));
+        it_p0 += __popcll(__ballot(active && phase == 0));
+        it_p1 += __popcll(__ballot(active && phase == 1));
+        it_p2 += __popcll(__ballot(active && phase == 2));
+#endif
         // ---- state 0: one material interaction, then the primitives that are not models
         if (active && phase == 0) {
             Rnd rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
@@ -730,7 +745,12 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 faces_j = sc.meshes[mesh_j].face_count;
                 root_j = sc.mesh_bvh_root[mesh_j];
             }
+#ifdef PT_WSTAT
+            it_walk_calls++;
+            if (mesh_bvh_steps<0>(sc, r, root_j, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits, nullptr, &ws)) {
+#else
             if (mesh_bvh_steps<0>(sc, r, root_j, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) {
+#endif
                 if (!MULTI) {
                     phase = 2;  // (the one job's result is merged in state 2, straight from the walk's registers)
                 } else {
@@ -806,6 +826,13 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
             }
         }
     }
+#ifdef PT_WSTAT
+    if (lane == 0 && npix) {
+        unsigned long long v[12] = {it_n, it_active, it_p0, it_p1, it_p2, it_walk_calls, ws.steps, ws.node_lanes, ws.hop_lanes,
+                                    ws.leaf_runs, ws.leaf_lanes, ws.idle_lanes};
+        for (int k = 0; k < 12; k++) atomicAdd(&wstat[k], v[k]);
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -1528,10 +1555,18 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
             dim3 gridw((units_for(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
             if (ctx->walk_jobs.n == 1)
                 hipLaunchKernelGGL(pt_samples_w<false>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
-                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u);
+                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u
+#ifdef PT_WSTAT
+                                   , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
+#endif
+                                   );
             else
                 hipLaunchKernelGGL(pt_samples_w<true>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
-                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n);
+                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n
+#ifdef PT_WSTAT
+                                   , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
+#endif
+                                   );
         } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
         else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
 #undef PT_CALL_PREFIX
@@ -1605,8 +1640,8 @@ int rt_create(int device, int width, int height, rt_context **out) {
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < rt_context::EV_RING; i++)
         if (hipEventCreate(&ctx->ev[i][0]) != hipSuccess || hipEventCreate(&ctx->ev[i][1]) != hipSuccess || hipEventCreate(&ctx->ev[i][2]) != hipSuccess) { ctx->error = "hipEventCreate failed"; return bail(RT_EHIP); }
-    if (hipMalloc((void **)&ctx->d_counters, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, (COUNTER_REPLICAS * COUNTER_STRIDE + 8) * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
+    if (hipMalloc((void **)&ctx->d_counters, (COUNTER_REPLICAS * COUNTER_STRIDE + 32) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, (COUNTER_REPLICAS * COUNTER_STRIDE + 32) * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
     if ((rc = rt_set_seed(ctx, 0xC0FFEEull)) != RT_OK) return bail(rc);
     if ((rc = rt_set_textures(ctx, nullptr, 0, 0, 0)) != RT_OK) return bail(rc);
@@ -2390,6 +2425,17 @@ int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]) {
         out[0] += h[(size_t)r * COUNTER_STRIDE + 14];
         out[1] += h[(size_t)r * COUNTER_STRIDE + 15];
     }
+#ifdef PT_WSTAT
+    {   // diagnostic build: lane census of pt_samples_w (tools/wstat.py)
+        unsigned long long v[12];
+        if (hipMemcpy(v, ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8, sizeof v, hipMemcpyDeviceToHost) == hipSuccess) {
+            const char *names[12] = {"outer iterations", "active lanes", "phase-0 lanes", "phase-1 lanes", "phase-2 lanes", "walk slices",
+                                     "walk steps", "node-test lanes", "hop lanes", "leaf phases", "leaf lanes", "finished (idle) lanes"};
+            for (int k = 0; k < 12; k++) fprintf(stderr, "[wstat] %-24s %llu\n", names[k], v[k]);
+            (void)hipMemset(ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8, 0, sizeof v);
+        }
+    }
+#endif
 #if PT_STAMPS
     {   // diagnostic build: print the s_memtime shares of pt_samples_q's sections
         unsigned long long st[8];
