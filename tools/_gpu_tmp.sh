@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for v in slot3 slot1b slot1 slot1c; do timeout -k 10 200 python3 tools/quick_bench.py --lib=opencl-raytracing_amd/variants/$v.so c2:64 c3:256 2>/dev/null || echo "$v failed"; done
+for i in 1 2; do
+timeout -k 10 200 python3 tools/quick_bench.py c2:64 2>/dev/null
+timeout -k 10 200 python3 tools/quick_bench.py --lib=opencl-raytracing_amd/variants/pre1.so c2:64 2>/dev/null
+timeout -k 10 200 python3 tools/quick_bench.py --lib=opencl-raytracing_amd/variants/pre2.so c2:64 2>/dev/null
+done
