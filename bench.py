@@ -135,7 +135,7 @@ def cpu_baseline(wl, table, budget_s=20.0):
                       "%.1f s wall" % (nb, rows, cw_s, W, H, spp_s, spp, samples / 1e6, wall)}
 
 
-def roofline(workload, main_ms, first_ms, call_ms, alg_bytes):
+def roofline(workload, main_ms, first_ms, call_ms, alg_bytes, share=1.0, valid=True):
     """VALU-issue roofline of the dominant kernel from profiles/valu_mix.json (class counts per launch x
     measured issue costs) and the kernel's live HIP-event time; see tools/summarize_profile.py."""
     peak = SIMDS * PEAK_CLOCK_GHZ                                   # G issue cycles / s
@@ -159,7 +159,14 @@ def roofline(workload, main_ms, first_ms, call_ms, alg_bytes):
             if name.startswith(main_key):
                 kern, out["kernel"] = k, name
     t = main_ms * 1e-3
+    if kern and not valid:
+        kern = None
+        out["note"] = "workload generator arguments overridden: the profiled instruction mix does not apply"
     if kern:
+        # N > 1: this rank traces `share` of the frame's pixel-samples (8x8 tiles interleaved: a uniform sample of
+        # the image), so it issues that share of the profiled single-GPU launch's instructions
+        kern = dict(kern, **{k: kern[k] * share for k in ("issue_cycles", "issue_cycles_low", "issue_cycles_high", "valu_insts")})
+        out["share_of_profiled_launch"] = round(share, 5)
         ach = kern["issue_cycles"] / t / 1e9
         lanes = kern.get("lanes_per_inst")
         out.update({
@@ -174,11 +181,11 @@ def roofline(workload, main_ms, first_ms, call_ms, alg_bytes):
             "profile_matches_source": mix.get("source_digest") == source_digest(),
             "scratch_bytes": kern.get("scratch_bytes"), "vgpr": kern.get("vgpr"),
         })
-        hbm = sum(k["hbm_bytes"] or 0 for k in mix["kernels"].values())
+        hbm = sum(k["hbm_bytes"] or 0 for k in mix["kernels"].values()) * share
         if hbm:
             out["traffic"] = int(hbm)
             out["hbm_frac"] = round(hbm / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-    else:
+    elif "note" not in out:
         out["note"] = "profiles/valu_mix.json has no entry for this workload: run tools/profile.sh + tools/summarize_profile.py"
     # round 1's figure, kept for continuity: the REFERENCE kernel's logical traffic (every primitive struct it
     # would have dereferenced) over the call time.  The scene lives in SGPRs / L2, so these bytes never move:
@@ -315,7 +322,9 @@ def main():
                                    ("; %s of the packed radiance tiles to rank 0 over RCCL" % args.exchange if world > 1 else ""),
                        "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED),
                        **({"workload_overrides": wl_args} if wl_args else {})},
-            "roofline": roofline(workload, float(np.mean(main_ms)), float(np.mean(first_ms)), call_ms, alg_bytes),
+            "roofline": roofline(workload, float(np.mean(main_ms)), float(np.mean(first_ms)), call_ms, alg_bytes,
+                                 share=my_samples / float(wl.width * wl.height * base_spp) / (spp // chunk),
+                                 valid=not wl_args and not args.spp),
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
             "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
         }
