@@ -404,6 +404,13 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 // three-state walk (from parent / from sibling / from child) replaces the stack.
 //   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = parent | split_axis << 28;
 //   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
+// 1 / d per axis for the slab tests of the BVH walks: the hardware reciprocal, its magnitude capped at 1e30 so that
+// o · (1/d) stays finite for an axis-parallel ray (±0 → ±1e30: every slab distance is then astronomically large or an
+// exact 0 — the same verdicts as with infinities, without their inf − inf)
+PT_DEV V3 cull_inverse(V3 d) {
+    V3 i = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    return mk(fminf(fmaxf(i.x, -1.0e30f), 1.0e30f), fminf(fmaxf(i.y, -1.0e30f), 1.0e30f), fminf(fmaxf(i.z, -1.0e30f), 1.0e30f));
+}
 template <bool COUNT>
 PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, uint32_t &best_id, LaneCounters *cn) {
     // per-ray constants of the culling tests: hardware rcp / sqrt (1 ulp) scaled to the safe side — the margins
@@ -412,7 +419,8 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     float c_ray = 2.0e-6f + 2.0f * fabsf(dd - 1.0f) * (__builtin_amdgcn_rcpf(fminf(dd, 1.0f)) * 1.000002f);
     float k_ray = __builtin_amdgcn_sqrtf(2.0f * c_ray) * 1.02f;   // margin per unit of distance to the node
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
-    V3 inv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    V3 inv = cull_inverse(r.d);
+    const V3 noi = mk(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));   // slab test: t = fma(plane, inv, -o·inv)
     // which child is nearer along each axis: bit k set → the RIGHT child (higher coordinates) first
     uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
@@ -456,17 +464,18 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
         float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
         float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
         float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
-        float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;  // approximate sqrt, rounded up
-        float m = k_ray * dfar + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
-        float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
+        // (culling arithmetic, not the reference's: fused multiply-adds — fewer instructions, smaller rounding)
+        float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;  // approximate sqrt, rounded up
+        float m = __builtin_fmaf(k_ray, dfar, __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f));
+        float t1 = __builtin_fmaf(a.x - m, inv.x, noi.x), t2 = __builtin_fmaf(b.x + m, inv.x, noi.x);
         float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
-        t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
+        t1 = __builtin_fmaf(a.y - m, inv.y, noi.y); t2 = __builtin_fmaf(b.y + m, inv.y, noi.y);
         tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-        t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
+        t1 = __builtin_fmaf(a.z - m, inv.z, noi.z); t2 = __builtin_fmaf(b.z + m, inv.z, noi.z);
         tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-        bool miss = tmin > tmax + fabsf(tmax) * 1.0e-5f + 1.0e-4f   // the line misses the box
-                    || tmax < -1.0e-2f                               // box entirely behind the origin
-                    || tmin > best_t * 1.00001f + 1.0e-2f;           // box entirely beyond the best hit
+        bool miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f   // the line misses the box
+                    || tmax < -1.0e-2f                                             // box entirely behind the origin
+                    || tmin > __builtin_fmaf(best_t, 1.00001f, 1.0e-2f);           // box entirely beyond the best hit
         bool leaf = (B & 0x80000000u) != 0;
         if (!miss && leaf) {  // park here: the spheres are tested in the leaf phase below
             at_leaf = true;

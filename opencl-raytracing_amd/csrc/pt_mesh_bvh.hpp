@@ -90,7 +90,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
     float dlen = __builtin_amdgcn_sqrtf(dot(r.d, r.d)) * 1.000001f;
     float inv_len = __builtin_amdgcn_rcpf(dlen);
     V3 dh = r.d * inv_len;
-    V3 inv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    V3 inv = cull_inverse(r.d);   // (the slab test keeps the subtract form here: three more live registers for -o·inv would spill)
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
     uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
@@ -161,12 +161,12 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                 float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
                 float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
                 float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
-                float dfar = __builtin_amdgcn_sqrtf(fx * fx + fy * fy + fz * fz) * 1.001f;
-                float reach = dfar + 2.0f * ex.z;
+                float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;
+                float reach = __builtin_fmaf(2.0f, ex.z, dfar);
                 // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
                 float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
                 float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
-                float m = fminf(m_steep, m_cap) + 1.0e-5f * (dfar + o_max) + 1.0e-6f;
+                float m = fminf(m_steep, m_cap) + __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f);
                 float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
                 float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
                 t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
@@ -174,7 +174,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                 t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
                 tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
                 // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
-                miss = tmin > tmax + fabsf(tmax) * 1.0e-5f + 1.0e-4f || tmax < -(m + 1.0f) ||
+                miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f || tmax < -(m + 1.0f) ||
                        tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
                 if (PT_MESH_SLAB && !miss && !steep && ex.x < PT_MESH_SLAB_SIN && sb > 0.5f && ex.w > 1.0e-3f) {
                     // Grazing subtree with a narrow cone: the displacement m_cap is real, but only ALONG the

@@ -93,6 +93,11 @@ PT_DEV void zero_counters(LaneCounters &cn) {
     for (int i = 0; i < PT_N_COUNTERS; i++) cn.c[i] = 0;
 }
 
+// how many set bits of a wave mask belong to lanes below this one (v_mbcnt: no per-lane mask to keep in registers)
+PT_DEV uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // xor-butterfly over the g lanes of a pixel group: a fixed summation tree
 PT_DEV V3 group_sum(V3 sum, uint32_t g) {
     for (uint32_t off = g >> 1; off > 0; off >>= 1) {
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_n[k];
         uint32_t pos = (blockIdx.x % LIVE_SEGMENTS) * fp.seg_cap + s_base + before +
-                       (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                       lanes_below(m);
         live[pos] = slot;
         recs[pos] = rec;
     }
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
         unsigned long long m = __ballot(need);
         // refill when enough lanes idle (or none is active): the refill step issues for the whole wave
         if (m && next < total && ((uint32_t)__popcll(m) >= PT_REFILL_MIN || m == ~0ull)) {
-            uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t cand = next + lanes_below(m);
             if (need && cand < total) {
                 idx = cand;
                 // pixel of this queue entry: p = idx / count, exactly, without an integer divide:
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
         bool need = !active;
         unsigned long long m = __ballot(need);
         if (m && next < total) {
-            uint32_t cand = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t cand = next + lanes_below(m);
             if (need && cand < total) {
                 idx = cand;
                 uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);  // = idx / count exactly (pt_samples_q)
