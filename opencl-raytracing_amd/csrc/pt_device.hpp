@@ -404,6 +404,13 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 // three-state walk (from parent / from sibling / from child) replaces the stack.
 //   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = parent | split_axis << 28;
 //   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
+// base + a 32-BIT byte offset: the compiler then uses the scalar-base form of the global load (one 32-bit shift
+// instead of 64-bit address arithmetic per access).  The host keeps every BVH array below 4 GiB (rt_set_scene).
+template <class T>
+PT_DEV const T *at32(const T *base, uint32_t byte_offset) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset);
+}
+
 // 1 / d per axis for the slab tests of the BVH walks: the hardware reciprocal, its magnitude capped at 1e30 so that
 // o · (1/d) stays finite for an axis-parallel ray (±0 → ±1e30: every slab distance is then astronomically large or an
 // exact 0 — the same verdicts as with infinities, without their inf − inf)
@@ -442,7 +449,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
             if (cur == 0) {
                 finished = true;
             } else {
-                uint32_t hA = __float_as_uint(sc.bvh_nodes[2 * cur].w);
+                uint32_t hA = __float_as_uint(at32(sc.bvh_nodes, cur << 5)->w);
                 uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
                 uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
                 if (cur == pnear) {
@@ -454,7 +461,8 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
             }
         }
       if (!finished && !at_leaf && state != FROM_CHILD) do {
-        float4 a = sc.bvh_nodes[2 * cur], b = sc.bvh_nodes[2 * cur + 1];
+        const float4 *nd2 = at32(sc.bvh_nodes, cur << 5);
+        float4 a = nd2[0], b = nd2[1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
         uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
@@ -502,8 +510,8 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                 uint32_t first = leaf_b & 0x0FFFFFFFu, cnt = (leaf_b >> 28) & 7u;
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
-                    float t = sphere_t(r, sc.bvh_sph[first + k]);
-                    uint32_t idx = sc.bvh_idx[first + k];
+                    float t = sphere_t(r, *at32(sc.bvh_sph, (first + k) << 4));
+                    uint32_t idx = *at32(sc.bvh_idx, (first + k) << 2);
                     if (t > 0.0f && (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK)))) {
                         best_t = t;
                         best_id = K_SPHERE | idx;

@@ -110,7 +110,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                 if (cur == root) {
                     finished = true;
                 } else {
-                    uint32_t hA = __float_as_uint(sc.mbvh_nodes[4 * (size_t)cur].w);
+                    uint32_t hA = __float_as_uint(at32(sc.mbvh_nodes, cur << 6)->w);
                     uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
                     uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
                     if (cur == pnear) {
@@ -130,7 +130,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
         }
 #endif
         if (!finished && state < FROM_CHILD) {
-        const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
+        const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
         float4 a = nd[0], b = nd[1];
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         uint32_t parent = A & 0x0FFFFFFFu;
@@ -220,13 +220,13 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
             if (ws) { ws->leaf_runs++; ws->leaf_lanes += __popcll(__ballot(parked)); }
 #endif
             if (parked) {
-                const float4 *nd = sc.mbvh_nodes + 4 * (size_t)cur;
+                const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
                 uint32_t A = __float_as_uint(nd[0].w), B = __float_as_uint(nd[1].w);
                 uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
                 for (uint32_t k = 0; k < cnt; k++) {
-                    uint32_t idx = sc.mbvh_face_idx[first + k];
+                    uint32_t idx = *at32(sc.mbvh_face_idx, (first + k) << 2);
                     if (idx >= best_face) continue;
-                    const float4 *fq = sc.mbvh_faces + 3 * (size_t)(first + k);
+                    const float4 *fq = at32(sc.mbvh_faces, (first + k) * 48u);
                     float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
 #ifndef PT_MESH_STAT
                     if (dbg) dbg->c[CN_DBG_BVH_TESTS]++;

@@ -1787,7 +1787,8 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
             roots[m] = mb.build();
             ctx->have_mesh_bvh = true;
         }
-        if (nodes.size() / 4 >= (1u << 28) || lidx.size() >= (1u << 28)) ctx->have_mesh_bvh = false;
+        // the walks address these arrays with 32-bit byte offsets (at32): everything below 4 GiB, node indices below 2^26
+        if (nodes.size() / 4 >= (1u << 26) || lidx.size() >= (1u << 26)) ctx->have_mesh_bvh = false;
         if (nodes.empty()) nodes.resize(4, make_float4(0, 0, 0, 0));
         if (lfaces.empty()) lfaces.resize(3, make_float4(0, 0, 0, 0));
         HIP_TRY(ctx, ctx->mbvh_nodes.upload(nodes.data(), nodes.size()));
@@ -1805,7 +1806,7 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (all_bvh && !jobs.empty() && jobs.size() < (1u << 16)) HIP_TRY(ctx, ctx->walk_jobs.upload(jobs.data(), jobs.size()));
     }
     ctx->bvh_node_count = 0;
-    if (d->sphere_count > 0 && d->sphere_count < (1u << 28)) {
+    if (d->sphere_count > 0 && d->sphere_count < (1u << 26)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
         bool finite = true;
         for (uint32_t i = 0; i < d->sphere_count && finite; i++)
             finite = std::isfinite(d->spheres[i].pos.x) && std::isfinite(d->spheres[i].pos.y) &&
