@@ -60,7 +60,7 @@ PT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 // the three numerators — the same operations with the same operands, hence the same bits, in 18 instead of 33
 // instructions.  If any active lane of the wave is outside that range the whole wave takes the compiler's
 // divisions (same bits for the in-range lanes, so the choice of path never shows in the result).
-// tests/test_gpu_units.py::test_div3_is_three_ieee_divisions compares the two paths on 2^28 operand sets.
+// tests/test_gpu_units.py::test_div3_is_three_ieee_divisions compares the two paths on 2^24 operand sets.
 #ifndef PT_DIV3
 #define PT_DIV3 0  // A/B on MI355X: bit-identical, 31 % fewer v_rcp and 15 % fewer fma issued, kernel time unchanged (C2 2.424 vs 2.418 ms)
 #endif
