@@ -31,7 +31,6 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with the extra o
   "cpu_baseline" the oracle (CPU restatement of the reference kernel) on this host's cores, bounded sample.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -71,12 +70,10 @@ def host_cores():
 
 
 def source_digest():
-    """Digest of the device sources: profiles/valu_mix.json records the one it was measured on."""
+    """Digest of the device sources (comments and white space ignored): profiles/valu_mix.json records the one it
+    was measured on."""
     import __graft_entry__ as g
-    h = hashlib.sha1()
-    for p in g.hip_sources():
-        h.update(open(p, "rb").read())
-    return h.hexdigest()[:16]
+    return g.device_source_digest()
 
 
 def cpu_baseline(wl, table, budget_s=20.0):

@@ -158,13 +158,9 @@ for name, m in sorted(per_kernel.items()):
 if mix_out:
     path = os.path.join(dst, "valu_mix.json")
     allmix = json.load(open(path)) if os.path.isfile(path) else {}
-    import hashlib
     import __graft_entry__ as g
-    h = hashlib.sha1()
-    for src_file in g.hip_sources():
-        h.update(open(src_file, "rb").read())
     # the device sources the counts were measured on: bench.py compares (profile_matches_source)
-    allmix[workload] = {"profile": tag, "kernels": mix_out, "source_digest": h.hexdigest()[:16]}
+    allmix[workload] = {"profile": tag, "kernels": mix_out, "source_digest": g.device_source_digest()}
     json.dump(allmix, open(path, "w"), indent=1, sort_keys=True)
     hb = [v["hbm_bytes"] for v in mix_out.values() if v["hbm_bytes"]]
     if hb:
