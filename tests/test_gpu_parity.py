@@ -162,3 +162,52 @@ def test_big_scene_crop(name, oracle, table):
     outside[(y0 // 8) * 8:((y0 + ch + 7) // 8) * 8, (x0 // 8) * 8:((x0 + cw + 7) // 8) * 8] = 0
     assert not outside.any()
     t.close()
+
+
+def fused_sum_in_kernel_order(per_sample, count):
+    """The accumulator the fused kernels must produce from per-sample radiances (n_pixels, count, 3) float32:
+    lane l of a group of g = min(64, 2^ceil(log2 count)) lanes adds its samples l, l+g, l+2g, … in that order, then an
+    xor butterfly (offsets g/2 … 1) combines the lanes — csrc/rt_amd.hip group_sum / pt_samples_q's final loop."""
+    g = 1
+    while g < count and g < 64:
+        g *= 2
+    n = per_sample.shape[0]
+    lanes = np.zeros((n, g, 3), np.float32)
+    for j in range(0, count, g):                       # sequential adds per lane
+        part = per_sample[:, j:j + g]
+        lanes[:, :part.shape[1]] = (lanes[:, :part.shape[1]] + part).astype(np.float32)
+    idx = np.arange(g)
+    off = g // 2
+    while off:
+        lanes = (lanes + lanes[:, idx ^ off]).astype(np.float32)
+        off //= 2
+    return lanes[:, 0]
+
+
+@pytest.mark.parametrize("name,kw,spp", [
+    ("c2", dict(width=96, height=54), 64),                           # pt_prefix + pt_samples_q<…, GEOM 0>, the headline regime
+    ("all_kinds", dict(width=80, height=48), 64),                    # lens + meshes below the BVH threshold: GEOM 1
+    ("c3", dict(width=64, height=36, tex_size=64), 256),             # 256 spp: four samples per lane, then the butterfly
+    ("c4", dict(width=64, height=36, n_spheres=3000), 64),           # sphere BVH instantiation
+    ("c5", dict(width=40, height=24, segments=24, rings=16), 512),   # pt_samples_w, one pixel per wave
+    ("c2", dict(width=61, height=35), 7),                            # ragged frame, count not a power of two
+])
+def test_timed_kernels_bit_exact_against_oracle_samples(name, kw, spp, oracle, table):
+    """The kernels bench.py times (pt_prefix + pt_samples_q / pt_samples_w: prefix sharing, in-wave queue, walk
+    slices), BIT FOR BIT against the oracle at the timed sample counts: the oracle supplies every pixel-sample's
+    radiance, summed here in the kernels' documented order; the fused accumulator must equal that sum exactly, and
+    the resolved linear image its IEEE quotient by the count."""
+    wl = rt.workloads.get(name, **kw)
+    W, H = wl.width, wl.height
+    t = rt.RayTracer(W, H, scene=wl.scene, seed=cases.SEED)
+    t.clear()
+    t.renderSamples(wl.camera, 0, spp)
+    t.sync()
+    lin = t.readLinear()
+    ys, xs, ss = np.meshgrid(np.arange(H), np.arange(W), np.arange(spp), indexing="ij")
+    per, _ = oracle.samples(wl.scene, wl.camera, table, W, H, xs.ravel(), ys.ravel(), ss.ravel())
+    exp_sum = fused_sum_in_kernel_order(per.reshape(H * W, spp, 3), spp).reshape(H, W, 3)
+    exp_lin = (exp_sum / np.float32(spp)).astype(np.float32)
+    assert np.array_equal(lin[..., :3].view(np.uint32), exp_lin.view(np.uint32))
+    assert (lin[..., 3] == 1.0).all() and (exp_sum.sum(-1) > 0).mean() > 0.1
+    t.close()
