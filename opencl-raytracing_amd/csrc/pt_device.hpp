@@ -331,8 +331,12 @@ PT_DEV Rnd fetch_rnd_b(const float *__restrict__ table, V3 dir, uint32_t depth, 
 enum : uint32_t { K_SPHERE = 0u << 30, K_PLANE = 1u << 30, K_LENS = 2u << 30, K_MESH = 3u << 30, K_MASK = 3u << 30 };
 #define PT_NO_HIT 0xFFFFFFFFu
 
+// The intersection routines return the accepted parameter t, or PT_MISS = +infinity: a caller looking for the
+// nearest hit then needs ONE comparison, `t < best_t` (best_t <= MAX_DISTANCE), instead of `t > 0 && t < best_t`
+// — a v_cmp costs as much as two multiplies on this chip (profiles/r02_valu_microbench.md).
+#define PT_MISS INFINITY
 // :149-174 with r² precomputed (same float product, computed once at upload).
-// Returns the accepted root, or a negative number.
+// Returns the accepted root, or PT_MISS.
 PT_DEV float sphere_root(float b, float cc, float dis);
 PT_DEV float sphere_t(const Ray &r, float4 s) {
     V3 oc = xyz(s) - r.o;
@@ -359,21 +363,21 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
 PT_DEV bool sphere_needs_roots(float b, float cc, float dis) {
     return dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > -4096.0f);
 }
-// :155-171 — the accepted root for dis > 0, or a negative number
+// :155-171 — the accepted root for dis > 0, or PT_MISS
 PT_DEV float sphere_roots(float b, float dis) {
     float d = sqrtf(dis);
-    float t = -1.0f;
+    float t = PT_MISS;
     float t0 = b - d;
     if (in_range(t0)) t = t0;
     else {
         float t1 = b + d;
         if (in_range(t1)) t = t1;
     }
-    return t;  // accepted roots are >= MIN_DISTANCE > 0
+    return t;
 }
-// second half of :149-174: the accepted root, or a negative number
+// second half of :149-174: the accepted root, or PT_MISS
 PT_DEV float sphere_root(float b, float cc, float dis) {
-    return sphere_needs_roots(b, cc, dis) ? sphere_roots(b, dis) : -1.0f;
+    return sphere_needs_roots(b, cc, dis) ? sphere_roots(b, dis) : PT_MISS;
 }
 PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis) {
     V3 oc = xyz(s) - r.o;
@@ -512,7 +516,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                     if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
                     float t = sphere_t(r, *at32(sc.bvh_sph, (first + k) << 4));
                     uint32_t idx = *at32(sc.bvh_idx, (first + k) << 2);
-                    if (t > 0.0f && (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK)))) {
+                    if (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK))) {
                         best_t = t;
                         best_id = K_SPHERE | idx;
                     }
@@ -554,7 +558,7 @@ PT_DEV float plane_t(const Ray &r, V3 p0, V3 n) {
     float a = dot(r.d, n);
     float b = dot(p0 - r.o, n);
     float t = b / a;
-    return in_range(t) ? t : -1.0f;
+    return in_range(t) ? t : PT_MISS;
 }
 
 // :196-255 — intersection of two spheres; which = 0 → surface 1 (p1,r1), 1 → surface 2
@@ -572,34 +576,34 @@ PT_DEV float lens_t(const Ray &r, const rt_lens &l, int *which) {
         float t1A = b1 - d1, t1B = b1 + d1, t2A = b2 - d2, t2B = b2 + d2;
         float t;
         int w;
-        if ((t1B < t2A) || (t2B < t1A)) return -1.0f;
+        if ((t1B < t2A) || (t2B < t1A)) return PT_MISS;
         else if (RT_MIN_DISTANCE <= t1A || RT_MIN_DISTANCE <= t2A) {
             if (t2A <= t1A) { w = 0; t = t1A; } else { w = 1; t = t2A; }
         } else if (RT_MIN_DISTANCE <= t1B && RT_MIN_DISTANCE <= t2B) {
             if (t1B <= t2B) { w = 0; t = t1B; } else { w = 1; t = t2B; }
-        } else return -1.0f;
+        } else return PT_MISS;
         if (t <= RT_MAX_DISTANCE) {
             *which = w;
             return t;
         }
     }
-    return -1.0f;
+    return PT_MISS;
 }
 
-// :257-289 — Möller–Trumbore without culling.  Returns t (>0) on a hit.
+// :257-289 — Möller–Trumbore without culling.  Returns t on a hit, PT_MISS otherwise.
 PT_DEV float triangle_t(const Ray &r, V3 A, V3 e1, V3 e2, float *u_out, float *v_out) {
     V3 h = cross(r.d, e2);
     float a = dot(e1, h);
-    if (a > -RT_TRIANGLE_EPSILON && a < RT_TRIANGLE_EPSILON) return -1.0f;
+    if (a > -RT_TRIANGLE_EPSILON && a < RT_TRIANGLE_EPSILON) return PT_MISS;
     float f = 1.0f / a;
     V3 s = r.o - A;
     float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return -1.0f;
+    if (u < 0.0f || u > 1.0f) return PT_MISS;
     V3 q = cross(s, e1);
     float v = f * dot(r.d, q);
-    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    if (v < 0.0f || u + v > 1.0f) return PT_MISS;
     float t = f * dot(e2, q);
-    if (!in_range(t)) return -1.0f;
+    if (!in_range(t)) return PT_MISS;
     *u_out = u;
     *v_out = v;
     return t;
@@ -676,7 +680,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
                 cand &= cand - 1u;
                 float4 w = c.lwin[2 * j];
                 float t = sphere_t(r, make_float4(w.x, w.y, w.z, w.w * w.w));  // r·r: the product the host stored in sph4
-                if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | j; }
+                if (t < best_t) { best_t = t; best_id = K_SPHERE | j; }
             }
         }
         brute = false;
@@ -706,7 +710,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
                         float bb = n0 ? b0 : (n1 ? b1 : (n2 ? b2 : b3));
                         float dd = n0 ? d0 : (n1 ? d1 : (n2 ? d2 : d3));
                         float t = sphere_roots(bb, dd);
-                        if (t > 0.0f && t < best_t) { best_t = t; best_id = K_SPHERE | (i + j); }
+                        if (t < best_t) { best_t = t; best_id = K_SPHERE | (i + j); }
                         n0 = n0 && j != 0u; n1 = n1 && j != 1u; n2 = n2 && j != 2u; n3 = n3 && j != 3u;
                     }
                 }
@@ -723,10 +727,10 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
                 t2 = sphere_t(r, a2);
                 t3 = sphere_t(r, a3);
             }
-            if (t0 > 0.0f && t0 < best_t) { best_t = t0; best_id = K_SPHERE | i; }
-            if (t1 > 0.0f && t1 < best_t) { best_t = t1; best_id = K_SPHERE | (i + 1); }
-            if (t2 > 0.0f && t2 < best_t) { best_t = t2; best_id = K_SPHERE | (i + 2); }
-            if (t3 > 0.0f && t3 < best_t) { best_t = t3; best_id = K_SPHERE | (i + 3); }
+            if (t0 < best_t) { best_t = t0; best_id = K_SPHERE | i; }
+            if (t1 < best_t) { best_t = t1; best_id = K_SPHERE | (i + 1); }
+            if (t2 < best_t) { best_t = t2; best_id = K_SPHERE | (i + 2); }
+            if (t3 < best_t) { best_t = t3; best_id = K_SPHERE | (i + 3); }
             a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
         }
     }
@@ -734,7 +738,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
     for (uint32_t i = 0; i < sc.plane_count; i++) {
         const rt_plane &p = sc.planes[i];
         float t = plane_t(r, ld3(p.pos), ld3(p.normal));
-        if (t > 0.0f && t < best_t) {
+        if (t < best_t) {
             best_t = t;
             best_id = K_PLANE | i;
         }
@@ -742,7 +746,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
     for (uint32_t i = 0; LENSES && i < sc.lens_count; i++) {
         int which;
         float t = lens_t(r, sc.lenses[i], &which);
-        if (t > 0.0f && t < best_t) {
+        if (t < best_t) {
             best_t = t;
             best_id = K_LENS | i;
         }
@@ -797,7 +801,7 @@ PT_DEV void hit_models(const Ctx &c, const Ray &r, Nearest &nb) {
                     V3 A = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
                     float u, v;
                     float t = triangle_t(r, A, e1, e2, &u, &v);
-                    if (t > 0.0f) {
+                    if (t < PT_MISS) {
                         if (COUNT) c.cn->c[CN_H_TRI]++;
                         V3 n = mk(q2.y, q2.z, q2.w);
                         if (dot(n, r.d) < 0.0f) {

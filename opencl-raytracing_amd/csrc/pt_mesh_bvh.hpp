@@ -233,7 +233,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
 #endif
                     float u, v;
                     float t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
-                    if (t > 0.0f) {
+                    if (t < PT_MISS) {
                         if (MODE == 1) hits++;
                         else if (dot(mk(q2.y, q2.z, q2.w), r.d) < 0.0f) {
                             best_face = idx;

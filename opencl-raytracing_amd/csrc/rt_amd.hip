@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void pt_debug_hit(DeviceScene sc, int kind, co
     } else {
         // a single primitive through the SAME (t, id) search + winner rebuild the trace kernels use
         uint32_t p = prim[i];
-        float t = -1.0f;
+        float t = PT_MISS;
         if (kind == 0) { const rt_sphere &sp = sc.spheres[p]; t = sphere_t(r, make_float4(sp.pos.x, sp.pos.y, sp.pos.z, sp.r * sp.r)); nb.id = K_SPHERE | p; }
         else if (kind == 1) { const rt_plane &pl = sc.planes[p]; t = plane_t(r, ld3(pl.pos), ld3(pl.normal)); nb.id = K_PLANE | p; }
         else if (kind == 2) { int which; t = lens_t(r, sc.lenses[p], &which); nb.id = K_LENS | p; }
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) void pt_debug_hit(DeviceScene sc, int kind, co
             t = triangle_t(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), &u, &v);
             nb.id = K_MESH | p; nb.face = face[i]; nb.u = u; nb.v = v; nb.mat = 0;
         }
-        if (t > 0.0f) {
+        if (t < PT_MISS) {
             nb.t = t;
             hit = hit_finish<false>(c, r, nb, h);
             if (kind == 4) h.mat = h.tex = 0;  // hitTriangle sets neither mat_ID (hitModel does, :314) nor texture_ID (hitMeshOut, :299)
