@@ -1,6 +1,7 @@
 // mesh_bvh_build.hpp — host-side builder of the per-mesh BVHs that pt_mesh_bvh.hpp walks.
-// Binned-SAH splits over face centroids, leaves of <= 4 faces; children in adjacent pairs (left at
-// an odd global index, every tree starts at an even index); per node: bounds, parent, split axis,
+// Binned-SAH splits over face centroids, small leaves; children in adjacent pairs (left at
+// an odd global index, every tree starts at an even index); per node: bounds, skip link (the node that
+// follows the subtree in left-before-right order: the walk is threaded, pt_mesh_bvh.hpp), split axis,
 // normal cone (axis, cos/sin of the half angle, widened by 1e-4 rad), smallest face index, longest
 // edge and the smallest quality q = sin(angle between the two edges) · shape factor of the subtree.
 #pragma once
@@ -63,7 +64,9 @@ struct MeshBvhBuilder {
         }
     }
 
-    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e, uint32_t parent_axis = 0) {
+    // skip: where the walk goes after this subtree.  depth: from level 32 on the split is the median, so the
+    // recursion (and rt_debug_check_accel's) ends within 27 more levels for the < 2^26 faces the ABI admits
+    void fill(uint32_t me, uint32_t skip, uint32_t b, uint32_t e, uint32_t depth = 0) {
         float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         double ax[3] = {0, 0, 0};
@@ -102,7 +105,7 @@ struct MeshBvhBuilder {
         if (degenerate) q = 0.0f;
         if (!std::isfinite(emax)) { emax = INFINITY; q = 0.0f; }
 
-        uint32_t A = parent | parent_axis << 30, B;  // the parent's split axis rides along (the walk's way back up)
+        uint32_t A = skip, B;
         if (e - b <= MESH_BVH_LEAF) {
             uint32_t first = (uint32_t)(leaf_faces->size() / 3);
             for (uint32_t i = b; i < e; i++) {
@@ -120,7 +123,7 @@ struct MeshBvhBuilder {
             constexpr int NB = 16;
             double best_cost = INFINITY;
             int best_ax = -1, best_bin = -1;
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 3 && depth < 32u; k++) {
                 float ext = chi[k] - clo[k];
                 if (!(ext > 0.0f)) continue;
                 struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
@@ -176,8 +179,8 @@ struct MeshBvhBuilder {
             nodes->resize(nodes->size() + 8);
             A |= (uint32_t)axis << 28;
             B = left;
-            fill(left, me, b, mid, (uint32_t)axis);
-            fill(left + 1, me, mid, e, (uint32_t)axis);
+            fill(left, left + 1u, b, mid, depth + 1u);
+            fill(left + 1, skip, mid, e, depth + 1u);
         }
         float4 *nd = nodes->data() + 4 * (size_t)me;
         nd[0] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
@@ -195,7 +198,7 @@ struct MeshBvhBuilder {
         if ((nodes->size() / 4) & 1u) nodes->resize(nodes->size() + 4, make_float4(0, 0, 0, 0));  // even start
         uint32_t root = (uint32_t)(nodes->size() / 4);
         nodes->resize(nodes->size() + 4);  // the root is even, so the child pairs that follow are (odd, even)
-        fill(root, root, 0, n_faces);
+        fill(root, 0x0FFFFFFFu, 0, n_faces);
         return root;
     }
 };

@@ -37,8 +37,7 @@
 // reference accepts 2–5 edge lengths away from the face through this walk.
 //
 // Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
-//   A = parent | split_axis << 28;  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
-// Stackless ordered traversal as in hit_spheres_bvh (children adjacent, left child odd).
+//   A = skip link (the node after this subtree; PT_MESH_END = none);  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
 // (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
 #pragma once
 
@@ -71,162 +70,152 @@
 // MODE 1: count  — number of faces with index < best_face whose hitTriangle succeeds (any
 //                  facing): the reference's H_tri counter needs the back-facing hits it
 //                  stepped over before its first front-facing one.
-// The walk is stackless, so (cur, state) is its whole position: mesh_bvh_steps advances it by at most
-// max_steps node visits and returns true once the tree is exhausted — a kernel can interleave walks of
-// different lengths with other work (pt_samples_w).  Start with cur = root, state = 0.
+// The walk keeps neither a stack nor a way back up: the tree is THREADED — every node carries the index of the node
+// that follows its subtree in the fixed left-before-right order (its "skip" link: the right sibling for a left child,
+// the parent's skip for a right child, PT_MESH_END for the root), so "next" is the left child after a hit on an inner
+// node and the skip link otherwise.  The rule wants the SMALLEST INDEX among the accepted faces, not the nearest, so
+// the order in which subtrees are visited changes nothing but how early `best_face` can prune by index (1 % of the
+// node tests on C5) — an ordered near-first walk paid for its order with a parent chase on the way back up.
+// MeshWalk is the walk's whole position; mesh_bvh_steps advances it by at most max_steps nodes and returns true once
+// the tree is exhausted — a kernel can interleave walks of different lengths with other work (pt_samples_w).
 #ifdef PT_WSTAT  // diagnostic build (tools/wstat.py): wave-level lane census of the walk, never timed
 struct WalkStat { unsigned long long steps, node_lanes, hop_lanes, leaf_runs, leaf_lanes, idle_lanes; };
 #define PT_WSTAT_ARG , WalkStat *ws = nullptr
 #else
 #define PT_WSTAT_ARG
 #endif
-template <int MODE>
-PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &cur, int &state,
-                           uint32_t &best_face, float &ft, float &fu, float &fv, uint32_t max_steps, uint32_t &hits,
-                           LaneCounters *dbg = nullptr PT_WSTAT_ARG) {
-    // Per-ray constants of the CULLING tests only (never of a face test): hardware sqrt / rcp (1 ulp) instead of the
-    // correctly rounded expansions (54 / 43 issue cycles each, profiles/r02_valu_microbench.md) — every use below
-    // carries a relative slack of 1e-5 or more, and dlen is rounded UP by 2^-20 where a larger value is the safe side.
-    float dlen = __builtin_amdgcn_sqrtf(dot(r.d, r.d)) * 1.000001f;
-    float inv_len = __builtin_amdgcn_rcpf(dlen);
-    V3 dh = r.d * inv_len;
-    V3 inv = cull_inverse(r.d);   // (the slab test keeps the subtract form here: three more live registers for -o·inv would spill)
-    float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
-    uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
-    // Walk states: the three of the stackless walk, plus "parked at a leaf whose box the ray meets" (entered from
-    // the parent / from the sibling).  "While-while": node steps for every lane that is not parked; the face tests
-    // of the parked lanes only every PT_MESH_LEAF_EVERY steps, at the end of the slice, or when every lane is parked
-    // or through — run in place, the leaf block (two Möller–Trumbore tests with their division) executed on about
-    // every second step for the one or two lanes that had just reached a leaf.
-    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD, LEAF_FROM_PARENT, LEAF_FROM_SIBLING };
-    bool finished = false;
-    for (uint32_t guard = 0; guard < max_steps; guard++) {  // every node is entered at most 3 times
-        // the way back up costs no step of its own: a lane that has finished a subtree hops (up to PT_MESH_HOPS
-        // times) until it stands at a sibling that is still to be entered.  cur's own header word holds its
-        // parent and its parent's split axis, and children are adjacent with the left one odd: no other node is read
-        for (int hop = 0; hop < PT_MESH_HOPS; hop++)
-            if (!finished && state == FROM_CHILD) {
-                if (cur == root) {
-                    finished = true;
-                } else {
-                    uint32_t hA = __float_as_uint(at32(sc.mbvh_nodes, cur << 6)->w);
-                    uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
-                    uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
-                    if (cur == pnear) {
-                        cur = (cur & 1u) ? cur + 1u : cur - 1u;
-                        state = FROM_SIBLING;
-                    } else {
-                        cur = hA & 0x0FFFFFFFu;
-                    }
-                }
+#define PT_MESH_END 0x0FFFFFFFu
+#define PT_MESH_PARKED 0x80000000u
+struct MeshWalk {
+    uint32_t cur;   // the node to be tested next | PT_MESH_PARKED: met leaf whose faces are still to be tested;  PT_MESH_END: through
+};
+PT_DEV MeshWalk mesh_walk_start(uint32_t root) { return MeshWalk{root}; }
+
+// Per-ray constants of the CULLING tests only (never of a face test): hardware sqrt / rcp (1 ulp) instead of the
+// correctly rounded expansions (54 / 43 issue cycles each, profiles/r02_valu_microbench.md) — every use below
+// carries a relative slack of 1e-5 or more, and dlen is rounded UP by 2^-20 where a larger value is the safe side.
+struct MeshCull {
+    float dlen, o_max;
+    V3 dh, inv;
+};
+PT_DEV MeshCull mesh_cull_setup(const Ray &r) {
+    MeshCull k;
+    k.dlen = __builtin_amdgcn_sqrtf(dot(r.d, r.d)) * 1.000001f;
+    k.dh = r.d * __builtin_amdgcn_rcpf(k.dlen);
+    k.inv = cull_inverse(r.d);   // (the slab test keeps the subtract form here: three more live registers for -o·inv would spill)
+    k.o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+    return k;
+}
+
+// May the subtree of this node be skipped?  (a, b, cn, ex = the node's four float4; see the proof sketch above)
+template <int MODE>
+PT_DEV bool mesh_node_miss(const Ray &r, const MeshCull &k, float4 a, float4 b, float4 cn, float4 ex, uint32_t best_face,
+                           LaneCounters *dbg) {
+    const float dlen = k.dlen, o_max = k.o_max;
+    const V3 dh = k.dh, inv = k.inv;
+    if (dbg) dbg->c[CN_DBG_BVH_NODES]++;
+    bool miss = __float_as_uint(ex.y) >= best_face;  // every face below has a larger index than the best
+    if (!miss) {
+        // smallest |cos(theta)| over the subtree's normal cone
+        float x = dot(dh, xyz(cn));
+        float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
+        float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
+        bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-3f;    // no face of the subtree can be grazed
+        // search mode wants FRONT-facing hits only (dot(n, d) < 0, :298): a subtree whose whole normal
+        // cone points along the ray (n·d̂ >= cos(psi + alpha) > 0, far above the rounding of the
+        // reference's own dot product) holds back faces only — the exit side of a closed mesh
+#ifdef PT_MESH_STAT  // diagnostic: which kind of node is entered (read through the face-test debug counter)
+        if (dbg) {
+            bool wide = ex.x >= PT_MESH_SLAB_SIN;
+            int kind = wide ? 1 : (steep ? 3 : 2);
+            if (kind == PT_MESH_STAT) dbg->c[CN_DBG_BVH_TESTS]++;
+        }
+#endif
+        bool backside = MODE == 0 && PT_MESH_BACKFACE_CULL && x * cn.w - sb * ex.x > 1.0e-3f;
+        if (backside) miss = true;
+        bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
+        if (!backside && (steep || capped)) {
+            float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
+            float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
+            float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
+            float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;
+            float reach = __builtin_fmaf(2.0f, ex.z, dfar);
+            // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
+            float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
+            float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
+            float m = fminf(m_steep, m_cap) + __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f);
+            float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
+            float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
+            t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+            t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+            // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
+            miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f || tmax < -(m + 1.0f) ||
+                   tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
+            if (PT_MESH_SLAB && !miss && !steep && ex.x < PT_MESH_SLAB_SIN && sb > 0.5f && ex.w > 1.0e-3f) {
+                // Grazing subtree with a narrow cone: the displacement m_cap is real, but only ALONG the
+                // sliver a grazing face projects to.  With barycentrics l_k >= -eta_k (eta_total =
+                // m_cap / emax) the line's coordinate along any x perpendicular to d leaves the face's
+                // own extent along x by at most eta_total * (that extent).  Along n' = the part of the
+                // cone axis perpendicular to d every face of the subtree is thin: an edge e is
+                // perpendicular to its normal, so |e . n'| <= |e| (sin alpha + |cos psi|) / sin psi.
+                V3 np = (xyz(cn) - dh * x) * __builtin_amdgcn_rcpf(sb);   // |x| <= sin(alpha) + tau here (sb > 0.5)
+                float hx = 0.5f * (b.x - a.x), hy = 0.5f * (b.y - a.y), hz = 0.5f * (b.z - a.z);
+                float rn = fabsf(np.x) * hx + fabsf(np.y) * hy + fabsf(np.z) * hz;
+                float dist = (r.o.x - 0.5f * (a.x + b.x)) * np.x + (r.o.y - 0.5f * (a.y + b.y)) * np.y +
+                             (r.o.z - 0.5f * (a.z + b.z)) * np.z;
+                float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) * (__builtin_amdgcn_rcpf(sb) * 1.000002f) +
+                           1.0e-5f * (dfar + o_max) + 1.0e-5f;
+                if (fabsf(dist) > rn * 1.0001f + mn) miss = true;
             }
+        }
+    }
+    return miss;
+}
+
+template <int MODE>
+PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uint32_t &best_face, float &ft, float &fu,
+                           float &fv, uint32_t max_steps, uint32_t &hits, LaneCounters *dbg = nullptr PT_WSTAT_ARG) {
+    const MeshCull k = mesh_cull_setup(r);
+    uint32_t cur = w.cur;
+    // "While-while": a node per step for every lane that is neither parked nor through; the face tests of the lanes
+    // parked at a leaf only every PT_MESH_LEAF_EVERY steps, at the end of the slice, or when every lane is parked or
+    // through (run in place, the two Möller–Trumbore tests with their division were executed on about every second
+    // step for the one or two lanes that had just reached a leaf).
+    for (uint32_t guard = 0; guard < max_steps; guard++) {   // every node is tested at most once
 #ifdef PT_WSTAT
         if (ws) {
             ws->steps++;
-            ws->hop_lanes += __popcll(__ballot(!finished && state == FROM_CHILD));
-            ws->node_lanes += __popcll(__ballot(!finished && state < FROM_CHILD));
-            ws->idle_lanes += __popcll(__ballot(finished));
+            ws->node_lanes += __popcll(__ballot(cur < PT_MESH_END));
+            ws->idle_lanes += __popcll(__ballot(cur == PT_MESH_END));
         }
 #endif
-        if (!finished && state < FROM_CHILD) {
-        const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
-        float4 a = nd[0], b = nd[1];
-        uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
-        uint32_t parent = A & 0x0FFFFFFFu;
-        uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
-        float4 cn = nd[2], ex = nd[3];
-        if (dbg) dbg->c[CN_DBG_BVH_NODES]++;
-        bool miss = __float_as_uint(ex.y) >= best_face;  // every face below has a larger index than the best
-        if (!miss) {
-            // smallest |cos(theta)| over the subtree's normal cone
-            float x = dot(dh, xyz(cn));
-            float sb = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x * x));
-            float cosmin = fabsf(x) * cn.w - sb * ex.x - 1.0e-5f;
-            bool steep = cosmin > PT_MESH_TAU && ex.w > 1.0e-3f;    // no face of the subtree can be grazed
-            // search mode wants FRONT-facing hits only (dot(n, d) < 0, :298): a subtree whose whole normal
-            // cone points along the ray (n·d̂ >= cos(psi + alpha) > 0, far above the rounding of the
-            // reference's own dot product) holds back faces only — the exit side of a closed mesh
-#ifdef PT_MESH_STAT  // diagnostic: which kind of node is entered (read through the face-test debug counter)
-            if (dbg) {
-                bool wide = ex.x >= PT_MESH_SLAB_SIN;
-                int kind = wide ? 1 : (steep ? 3 : 2);
-                if (kind == PT_MESH_STAT) dbg->c[CN_DBG_BVH_TESTS]++;
-            }
-#endif
-            bool backside = MODE == 0 && PT_MESH_BACKFACE_CULL && x * cn.w - sb * ex.x > 1.0e-3f;
-            if (backside) miss = true;
-            bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
-            if (!backside && (steep || capped)) {
-                float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
-                float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
-                float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
-                float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;
-                float reach = __builtin_fmaf(2.0f, ex.z, dfar);
-                // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
-                float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
-                float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
-                float m = fminf(m_steep, m_cap) + __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f);
-                float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
-                float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
-                t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
-                tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-                t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
-                tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-                // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
-                miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f || tmax < -(m + 1.0f) ||
-                       tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
-                if (PT_MESH_SLAB && !miss && !steep && ex.x < PT_MESH_SLAB_SIN && sb > 0.5f && ex.w > 1.0e-3f) {
-                    // Grazing subtree with a narrow cone: the displacement m_cap is real, but only ALONG the
-                    // sliver a grazing face projects to.  With barycentrics l_k >= -eta_k (eta_total =
-                    // m_cap / emax) the line's coordinate along any x perpendicular to d leaves the face's
-                    // own extent along x by at most eta_total * (that extent).  Along n' = the part of the
-                    // cone axis perpendicular to d every face of the subtree is thin: an edge e is
-                    // perpendicular to its normal, so |e . n'| <= |e| (sin alpha + |cos psi|) / sin psi.
-                    V3 np = (xyz(cn) - dh * x) * __builtin_amdgcn_rcpf(sb);   // |x| <= sin(alpha) + tau here (sb > 0.5)
-                    float hx = 0.5f * (b.x - a.x), hy = 0.5f * (b.y - a.y), hz = 0.5f * (b.z - a.z);
-                    float rn = fabsf(np.x) * hx + fabsf(np.y) * hy + fabsf(np.z) * hz;
-                    float dist = (r.o.x - 0.5f * (a.x + b.x)) * np.x + (r.o.y - 0.5f * (a.y + b.y)) * np.y +
-                                 (r.o.z - 0.5f * (a.z + b.z)) * np.z;
-                    float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) * (__builtin_amdgcn_rcpf(sb) * 1.000002f) +
-                               1.0e-5f * (dfar + o_max) + 1.0e-5f;
-                    if (fabsf(dist) > rn * 1.0001f + mn) miss = true;
-                }
-            }
-        }
-        bool leaf = (B & 0x80000000u) != 0;
-        if (!miss && leaf) {
-            state = state == FROM_PARENT ? LEAF_FROM_PARENT : LEAF_FROM_SIBLING;   // park: faces in the leaf phase
-        } else if (!miss) {
-            uint32_t axis = (A >> 28) & 3u;
-            cur = B + ((far_first >> axis) & 1u);
-            state = FROM_PARENT;
-        } else if (cur == root) {
-            finished = true;
-        } else if (state == FROM_PARENT) {
-            cur = sibling;
-            state = FROM_SIBLING;
-        } else {
-            cur = parent;
-            state = FROM_CHILD;
-        }
+        if (cur < PT_MESH_END) {
+            const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
+            float4 a = nd[0], b = nd[1], cn = nd[2], ex = nd[3];
+            const uint32_t B = __float_as_uint(b.w);
+            if (mesh_node_miss<MODE>(r, k, a, b, cn, ex, best_face, dbg)) cur = __float_as_uint(a.w) & PT_MESH_END;
+            else if (B & 0x80000000u) cur |= PT_MESH_PARKED;
+            else cur = B;
         }
         // ---- leaf phase (wave-uniform decision)
-        const bool parked = !finished && state > FROM_CHILD;
+        const bool parked = (cur & PT_MESH_PARKED) != 0;
         const bool flush = (guard & (PT_MESH_LEAF_EVERY - 1u)) == PT_MESH_LEAF_EVERY - 1u || guard + 1u == max_steps ||
-                           __all(finished || parked);
+                           __all(cur >= PT_MESH_END);
         if (flush && __any(parked)) {
 #ifdef PT_WSTAT
             if (ws) { ws->leaf_runs++; ws->leaf_lanes += __popcll(__ballot(parked)); }
 #endif
             if (parked) {
-                const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
+                const float4 *nd = at32(sc.mbvh_nodes, (cur & PT_MESH_END) << 6);
                 uint32_t A = __float_as_uint(nd[0].w), B = __float_as_uint(nd[1].w);
                 uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
-                for (uint32_t k = 0; k < cnt; k++) {
-                    uint32_t idx = *at32(sc.mbvh_face_idx, (first + k) << 2);
+                for (uint32_t j = 0; j < cnt; j++) {
+                    uint32_t idx = *at32(sc.mbvh_face_idx, (first + j) << 2);
                     if (idx >= best_face) continue;
-                    const float4 *fq = at32(sc.mbvh_faces, (first + k) * 48u);
+                    const float4 *fq = at32(sc.mbvh_faces, (first + j) * 48u);
                     float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
 #ifndef PT_MESH_STAT
                     if (dbg) dbg->c[CN_DBG_BVH_TESTS]++;
@@ -241,27 +230,20 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, uint32_t root, u
                         }
                     }
                 }
-                if (cur == root) {
-                    finished = true;   // the root is a leaf
-                } else if (state == LEAF_FROM_PARENT) {
-                    cur = (cur & 1u) ? cur + 1u : cur - 1u;
-                    state = FROM_SIBLING;
-                } else {
-                    cur = A & 0x0FFFFFFFu;
-                    state = FROM_CHILD;
-                }
+                cur = A & PT_MESH_END;
             }
         }
-        if (__all(finished)) break;
+        if (__all(cur == PT_MESH_END)) break;
     }
-    return finished;
+    w.cur = cur;
+    return cur == PT_MESH_END;
 }
 
 template <int MODE>
 PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
                               float &fu, float &fv, LaneCounters *dbg = nullptr) {
-    uint32_t cur = root, hits = 0;
-    int state = 0;
-    (void)mesh_bvh_steps<MODE>(sc, r, root, cur, state, best_face, ft, fu, fv, 0x7FFFFFFFu, hits, dbg);
+    MeshWalk w = mesh_walk_start(root);
+    uint32_t hits = 0;
+    (void)mesh_bvh_steps<MODE>(sc, r, w, best_face, ft, fu, fv, 0x7FFFFFFFu, hits, dbg);
     return hits;
 }

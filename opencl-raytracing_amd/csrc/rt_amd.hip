@@ -644,8 +644,8 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     uint32_t hmat = 0;
     float nb_t = RT_MAX_DISTANCE;       // nearest sphere / plane / lens of the current bounce
     uint32_t nb_id = PT_NO_HIT;
-    uint32_t wcur = 0, wbest = 0;       // the walk's position and its best face so far
-    int wstate = 0;
+    MeshWalk wpos = mesh_walk_start(0);  // the walk's position and its best face so far
+    uint32_t wbest = 0;
     float wt = 0.0f, wu = 0.0f, wv = 0.0f;
     uint32_t job = 0;                   // MULTI: the job being walked, and the winning mesh hit so far
     uint32_t nb_face = 0, nb_mat = 0;
@@ -731,8 +731,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                     nb_face = nb_mat = 0;
                     nb_u = nb_v = 0.0f;
                 }
-                wcur = root0;
-                wstate = 0;
+                wpos = mesh_walk_start(root0);
                 wbest = faces0;
                 wt = wu = wv = 0.0f;
                 job = 0;
@@ -742,19 +741,18 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
         // ---- state 1: a slice of the current job's mesh walk
         if (active && phase == 1) {
             uint32_t hits = 0;
-            uint32_t mesh_j = mesh0, mat_j = mat0, faces_j = faces0, root_j = root0;
+            uint32_t mesh_j = mesh0, mat_j = mat0, faces_j = faces0;
             if (MULTI) {
                 uint2 jb = jobs[job];
                 mesh_j = jb.x;
                 mat_j = jb.y;
                 faces_j = sc.meshes[mesh_j].face_count;
-                root_j = sc.mesh_bvh_root[mesh_j];
             }
 #ifdef PT_WSTAT
             it_walk_calls++;
-            if (mesh_bvh_steps<0>(sc, r, root_j, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits, nullptr, &ws)) {
+            if (mesh_bvh_steps<0>(sc, r, wpos, wbest, wt, wu, wv, PT_WALK_STEPS, hits, nullptr, &ws)) {
 #else
-            if (mesh_bvh_steps<0>(sc, r, root_j, wcur, wstate, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) {
+            if (mesh_bvh_steps<0>(sc, r, wpos, wbest, wt, wu, wv, PT_WALK_STEPS, hits)) {
 #endif
                 if (!MULTI) {
                     phase = 2;  // (the one job's result is merged in state 2, straight from the walk's registers)
@@ -770,8 +768,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 job++;
                 if (MULTI && job < n_jobs) {  // next mesh: stay in state 1
                     uint32_t mesh_n = jobs[job].x;
-                    wcur = sc.mesh_bvh_root[mesh_n];
-                    wstate = 0;
+                    wpos = mesh_walk_start(sc.mesh_bvh_root[mesh_n]);
                     wbest = sc.meshes[mesh_n].face_count;
                     wt = wu = wv = 0.0f;
                 } else {
@@ -2108,6 +2105,53 @@ std::string host_walk(const std::vector<float4> &nodes, uint32_t stride, uint32_
     }
 }
 
+// the mesh trees are threaded (pt_mesh_bvh.hpp): follow "left child after an inner node, skip link after a leaf"
+std::string host_walk_threaded(const std::vector<float4> &nodes, uint32_t root, std::vector<uint32_t> &leaf_visits, BvhWalkStats &st) {
+    uint32_t n_nodes = (uint32_t)(nodes.size() / 4), cur = root;
+    for (uint64_t guard = 0; cur != 0x0FFFFFFFu; guard++) {
+        if (guard > (uint64_t)n_nodes + 8) return "walk does not terminate";
+        if (cur >= n_nodes) return "node index out of range";
+        uint32_t A, B;
+        memcpy(&A, &nodes[4 * (size_t)cur].w, 4);
+        memcpy(&B, &nodes[4 * (size_t)cur + 1].w, 4);
+        st.nodes++;
+        if (B & 0x80000000u) {
+            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+            st.leaves++;
+            for (uint32_t k = 0; k < cnt; k++) {
+                if (first + k >= leaf_visits.size()) return "leaf slot out of range";
+                leaf_visits[first + k]++;
+            }
+            cur = A & 0x0FFFFFFFu;
+        } else {
+            cur = B;
+        }
+    }
+    return "";
+}
+
+// recursive structural check of a threaded tree: child boxes inside the parent's, skip links, depth
+std::string host_check_threaded(const std::vector<float4> &nodes, uint32_t me, uint32_t parent, uint32_t skip, bool is_root,
+                                uint32_t depth, BvhWalkStats &st) {
+    const float4 &lo = nodes[4 * (size_t)me], &hi = nodes[4 * (size_t)me + 1];
+    uint32_t A, B;
+    memcpy(&A, &lo.w, 4);
+    memcpy(&B, &hi.w, 4);
+    if ((A & 0x0FFFFFFFu) != skip) return "wrong skip link";
+    st.max_depth = std::max<uint64_t>(st.max_depth, depth);
+    if (depth > 60) return "tree deeper than 60 levels";
+    if (!is_root) {
+        const float4 &plo = nodes[4 * (size_t)parent], &phi = nodes[4 * (size_t)parent + 1];
+        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
+            return "child box not inside its parent's";
+    }
+    if (B & 0x80000000u) return "";
+    if (!(B & 1u)) return "left child at an even index";
+    std::string e = host_check_threaded(nodes, B, me, B + 1u, false, depth + 1, st);
+    if (e.empty()) e = host_check_threaded(nodes, B + 1u, me, skip, false, depth + 1, st);
+    return e;
+}
+
 // recursive structural check: child boxes inside the parent's, parent links, depth
 std::string host_check_tree(const std::vector<float4> &nodes, uint32_t stride, uint32_t me, uint32_t parent, bool is_root,
                             uint32_t depth, BvhWalkStats &st) {
@@ -2194,12 +2238,12 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
         mb.leaf_idx = &lidx;
         uint32_t root = mb.build();
         BvhWalkStats st;
-        std::string e = host_check_tree(nodes, 4, root, root, true, 0, st);
+        std::string e = host_check_threaded(nodes, root, root, 0x0FFFFFFFu, true, 0, st);
         if (!e.empty()) return bad("mesh bvh: " + e);
-        for (uint32_t oct = 0; oct < 8; oct++) {
+        {
             std::vector<uint32_t> visits(lidx.size(), 0);
             BvhWalkStats w;
-            e = host_walk(nodes, 4, root, oct, visits, w);
+            e = host_walk_threaded(nodes, root, visits, w);
             if (!e.empty()) return bad("mesh bvh: " + e);
             for (uint32_t v : visits) if (v != 1) return bad("mesh bvh: a leaf slot is not visited exactly once");
             st.nodes = w.nodes; st.leaves = w.leaves;
