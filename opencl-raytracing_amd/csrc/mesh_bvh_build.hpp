@@ -175,9 +175,8 @@ struct MeshBvhBuilder {
                     return cp[3 * i + axis] < cp[3 * j + axis] || (cp[3 * i + axis] == cp[3 * j + axis] && i < j);
                 });
             }
-            uint32_t left = (uint32_t)(nodes->size() / 4);  // odd (trees start even, pairs follow)
+            uint32_t left = (uint32_t)(nodes->size() / 4);  // the two children are adjacent
             nodes->resize(nodes->size() + 8);
-            A |= (uint32_t)axis << 28;
             B = left;
             fill(left, left + 1u, b, mid, depth + 1u);
             fill(left + 1, skip, mid, e, depth + 1u);
@@ -195,9 +194,9 @@ struct MeshBvhBuilder {
     // → global index of the tree's root
     uint32_t build() {
         prepare();
-        if ((nodes->size() / 4) & 1u) nodes->resize(nodes->size() + 4, make_float4(0, 0, 0, 0));  // even start
+        if (!((nodes->size() / 4) & 1u)) nodes->resize(nodes->size() + 4, make_float4(0, 0, 0, 0));  // odd start
         uint32_t root = (uint32_t)(nodes->size() / 4);
-        nodes->resize(nodes->size() + 4);  // the root is even, so the child pairs that follow are (odd, even)
+        nodes->resize(nodes->size() + 4);  // the root is odd, so the child pairs that follow are (even, odd): one 128-byte line
         fill(root, 0x0FFFFFFFu, 0, n_faces);
         return root;
     }

@@ -170,9 +170,10 @@ struct DeviceScene {
     const uint32_t *mbvh_face_idx;  // their face index inside the mesh
     const uint32_t *mesh_bvh_root;  // per mesh
     // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
-    const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
+    const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, split axis << 28), (hi.xyz, left child | leaf)
     const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
     const uint32_t *bvh_idx;   // their original indices
+    const uint32_t *bvh_skips; // 8 per node: where a ray of direction octant o goes after the node's subtree (hit_spheres_bvh)
     uint32_t bvh_node_count;
     float bvh_lo[3], bvh_hi[3];  // bounds of all sphere CENTRES
     float bvh_rmax;              // largest radius
@@ -345,9 +346,7 @@ PT_DEV float sphere_t(const Ray &r, float4 s) {
     float dis = b * b - cc;
     return sphere_root(b, cc, dis);
 }
-#ifndef PT_SPHERE_HOPS
-#define PT_SPHERE_HOPS 1  // A/B on C4 at 8 spp: 1 → 78.6 ms, 2 → 79.4, 3 → 82.9, 4 → 85.3 (and 95.4 with a hop per step)
-#endif
+#define PT_BVH_END 0x0FFFFFFFu
 #ifndef PT_SPHERE_LEAF_EVERY
 #define PT_SPHERE_LEAF_EVERY 4u  // node steps between leaf phases of the sphere BVH walk (power of two)
 #endif
@@ -432,47 +431,28 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
     V3 inv = cull_inverse(r.d);
     const V3 noi = mk(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));   // slab test: t = fma(plane, inv, -o·inv)
-    // which child is nearer along each axis: bit k set → the RIGHT child (higher coordinates) first
-    uint32_t far_first = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
+    // the ray's direction octant: bit k set → along axis k the RIGHT child (higher coordinates) is the nearer one
+    const uint32_t oct = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
-    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
-    uint32_t cur = 0;
-    int state = FROM_PARENT;
-    const uint32_t n_nodes = sc.bvh_node_count;
-    // "while-while": node steps for every lane that is not parked at a leaf; the sphere tests of the parked
-    // lanes only every PT_SPHERE_LEAF_EVERY steps, or when every lane is parked or through.  In place, the leaf
-    // block (up to four sphere tests with their square roots) ran on almost every step for one or two lanes.
-    bool finished = false, at_leaf = false;
-    uint32_t leaf_b = 0, leaf_parent = 0;
-    for (uint32_t guard = 0; guard < 3u * n_nodes + 8u; guard++) {  // every node is entered at most 3 times
-      // the way back up costs no step of its own: a lane that has finished a subtree hops (up to twice) until
-      // it stands at a sibling that is still to be entered — (cur's own header word holds its parent, its
-      // parent's split axis, and children are adjacent with the left one odd, so no other node is read)
-      for (int hop = 0; hop < PT_SPHERE_HOPS; hop++)
-        if (!finished && !at_leaf && state == FROM_CHILD) {
-            if (cur == 0) {
-                finished = true;
-            } else {
-                uint32_t hA = __float_as_uint(at32(sc.bvh_nodes, cur << 5)->w);
-                uint32_t pleft = (cur & 1u) ? cur : cur - 1u;
-                uint32_t pnear = pleft + ((far_first >> (hA >> 30)) & 1u);
-                if (cur == pnear) {
-                    cur = (cur & 1u) ? cur + 1u : cur - 1u;
-                    state = FROM_SIBLING;
-                } else {
-                    cur = hA & 0x0FFFFFFFu;
-                }
-            }
-        }
-      if (!finished && !at_leaf && state != FROM_CHILD) do {
+    // The tree is THREADED per octant: a node carries, for each of the 8 sign patterns of a direction, the node that
+    // follows its subtree in that octant's near-before-far order (the sibling for the child entered first, the
+    // parent's link for the other, PT_BVH_END after the last) — so "next" is the nearer child after a hit on an
+    // inner node and the octant's skip link otherwise: no way back up, no state, every box tested at most once.
+    // "While-while": a node per step for every lane that is neither parked at a leaf nor through; the sphere tests
+    // of the parked lanes only every PT_SPHERE_LEAF_EVERY steps, or when every lane is parked or through.  In
+    // place, the leaf block (up to four sphere tests with their square roots) ran on almost every step for one or
+    // two lanes.
+    uint32_t cur = 1u;   // (the root; node 0 is padding so that sibling pairs start at even indices)
+    bool at_leaf = false;
+    uint32_t leaf_b = 0, leaf_skip = 0;
+    for (uint32_t guard = 0; guard < sc.bvh_node_count + 8u; guard++) {  // every node is tested at most once
+      if (cur != PT_BVH_END && !at_leaf) {
         const float4 *nd2 = at32(sc.bvh_nodes, cur << 5);
         float4 a = nd2[0], b = nd2[1];
+        const uint32_t skip = *at32(sc.bvh_skips, (cur << 5) + (oct << 2));   // (its own array: 32-byte boxes keep a sibling pair in one 64-byte stretch — C4 at 16 spp 132.3 → 117.8 ms against links inside a 64-byte node)
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
-        uint32_t parent = A & 0x0FFFFFFFu;
-        uint32_t sibling = (cur & 1u) ? cur + 1u : cur - 1u;
         if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
-        // entering `cur` from its parent or its sibling: slab test against the inflated box
-        // (fminf/fmaxf drop the NaN of 0·inf)
+        // slab test against the inflated box (fminf/fmaxf drop the NaN of 0·inf)
         float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
         float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
         float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
@@ -488,27 +468,18 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
         bool miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f   // the line misses the box
                     || tmax < -1.0e-2f                                             // box entirely behind the origin
                     || tmin > __builtin_fmaf(best_t, 1.00001f, 1.0e-2f);           // box entirely beyond the best hit
-        bool leaf = (B & 0x80000000u) != 0;
-        if (!miss && leaf) {  // park here: the spheres are tested in the leaf phase below
+        if (miss) {
+            cur = skip;
+        } else if (B & 0x80000000u) {  // park here: the spheres are tested in the leaf phase below
             at_leaf = true;
             leaf_b = B;
-            leaf_parent = parent;
-        } else if (!miss) {  // descend to the near child
-            uint32_t axis = (A >> 28) & 3u;
-            cur = B + ((far_first >> axis) & 1u);
-            state = FROM_PARENT;
-        } else if (cur == 0) {
-            finished = true;  // the root was missed
-        } else if (state == FROM_PARENT) {
-            cur = sibling;
-            state = FROM_SIBLING;
-        } else {
-            cur = parent;
-            state = FROM_CHILD;
+            leaf_skip = skip;
+        } else {                       // descend to the nearer child
+            cur = B + ((oct >> ((A >> 28) & 3u)) & 1u);
         }
-      } while (false);
+      }
         // ---- leaf phase (wave-uniform decision)
-        bool flush = (guard & (PT_SPHERE_LEAF_EVERY - 1u)) == PT_SPHERE_LEAF_EVERY - 1u || __all(at_leaf || finished);
+        bool flush = (guard & (PT_SPHERE_LEAF_EVERY - 1u)) == PT_SPHERE_LEAF_EVERY - 1u || __all(at_leaf || cur == PT_BVH_END);
         if (flush && __any(at_leaf)) {
             if (at_leaf) {
                 uint32_t first = leaf_b & 0x0FFFFFFFu, cnt = (leaf_b >> 28) & 7u;
@@ -522,18 +493,10 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                     }
                 }
                 at_leaf = false;
-                if (cur == 0) {
-                    finished = true;  // the root is a leaf
-                } else if (state == FROM_PARENT) {
-                    cur = (cur & 1u) ? cur + 1u : cur - 1u;
-                    state = FROM_SIBLING;
-                } else {
-                    cur = leaf_parent;
-                    state = FROM_CHILD;
-                }
+                cur = leaf_skip;
             }
         }
-        if (__all(finished)) break;
+        if (__all(cur == PT_BVH_END)) break;
     }
 }
 

@@ -1077,10 +1077,12 @@ void make_table(uint64_t seed, float *out) {
 #ifndef SPHERE_BVH_LEAF
 #define SPHERE_BVH_LEAF 4  // spheres per leaf (<= 7)
 #endif
+#define BVH_END 0x0FFFFFFFu
+#define BVH_ROOT 1u
 struct BvhBuild {
     const rt_sphere *sph;
     std::vector<uint32_t> order;
-    std::vector<float4> nodes;   // 2 per node
+    std::vector<float4> nodes;   // 4 per node: (lo, A) (hi, B) and the eight skip links (pt_device.hpp hit_spheres_bvh)
     std::vector<float4> leaf_sph;
     std::vector<uint32_t> leaf_idx;
 
@@ -1096,10 +1098,12 @@ struct BvhBuild {
             }
         }
     }
-    void fill(uint32_t me, uint32_t parent, uint32_t b, uint32_t e, uint32_t parent_axis = 0) {
+    // skip[o]: the node that follows this subtree for a ray of direction octant o (bit k of o: d_k < 0), whose walk
+    // enters the nearer child of every inner node first; BVH_END after the last one
+    void fill(uint32_t me, const uint32_t skip[8], uint32_t b, uint32_t e, uint32_t depth = 0) {
         float lo[3], hi[3];
         bounds(b, e, lo, hi);
-        uint32_t A = parent | parent_axis << 30, B;  // the parent's split axis rides along: the walk's way back up needs no parent load
+        uint32_t A = 0, B;
         if (e - b <= SPHERE_BVH_LEAF) {
             uint32_t first = (uint32_t)leaf_sph.size();
             for (uint32_t i = b; i < e; i++) {
@@ -1124,7 +1128,7 @@ struct BvhBuild {
             constexpr int NB = 16;
             double best_cost = INFINITY;
             int best_ax = -1, best_bin = -1;
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 3 && depth < 32u; k++) {   // (median splits from level 32 on bound the depth)
                 float ext = chi[k] - clo[k];
                 if (!(ext > 0.0f)) continue;
                 struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
@@ -1179,21 +1183,29 @@ struct BvhBuild {
                     return ci[ax] < cj[ax] || (ci[ax] == cj[ax] && i < j);
                 });
             }
-            uint32_t left = (uint32_t)(nodes.size() / 2);  // odd: the root is node 0 and pairs follow
-            nodes.resize(nodes.size() + 4);
-            A |= (uint32_t)ax << 28;
+            uint32_t left = (uint32_t)(nodes.size() / 4);  // even: the root is node 1 and pairs follow, each in one 64-byte stretch
+            nodes.resize(nodes.size() + 8);
+            A = (uint32_t)ax << 28;
             B = left;
-            fill(left, me, b, mid, (uint32_t)ax);
-            fill(left + 1, me, mid, e, (uint32_t)ax);
+            uint32_t skip_l[8], skip_r[8];
+            for (uint32_t o = 0; o < 8; o++) {   // the walk enters child B + ((o >> ax) & 1) first, its sibling next
+                bool right_first = ((o >> ax) & 1u) != 0;
+                skip_l[o] = right_first ? skip[o] : left + 1u;
+                skip_r[o] = right_first ? left : skip[o];
+            }
+            fill(left, skip_l, b, mid, depth + 1u);
+            fill(left + 1, skip_r, mid, e, depth + 1u);
         }
-        nodes[2 * me] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-        nodes[2 * me + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-        memcpy(&nodes[2 * me].w, &A, 4);
-        memcpy(&nodes[2 * me + 1].w, &B, 4);
+        nodes[4 * (size_t)me] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        nodes[4 * (size_t)me + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        memcpy(&nodes[4 * (size_t)me].w, &A, 4);
+        memcpy(&nodes[4 * (size_t)me + 1].w, &B, 4);
+        memcpy(&nodes[4 * (size_t)me + 2], skip, 32);
     }
     void build(uint32_t b, uint32_t e) {
-        nodes.resize(2);
-        fill(0, 0, b, e);
+        nodes.assign(8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // node 0 is padding, the root is node BVH_ROOT
+        const uint32_t end[8] = {BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END};
+        fill(BVH_ROOT, end, b, e);
     }
 };
 
@@ -1274,7 +1286,7 @@ struct rt_context {
     DevBuf<uint32_t> mbvh_face_idx, mesh_bvh_root;
     bool have_mesh_bvh = false;
     DevBuf<float4> bvh_nodes, bvh_sph;
-    DevBuf<uint32_t> bvh_idx;
+    DevBuf<uint32_t> bvh_idx, bvh_skips;
     uint32_t bvh_node_count = 0;
     float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0}, bvh_rmax = 0;
     int accel = 1;  // RT_OPT_ACCEL: 0 brute force, 1 BVH for >= ACCEL_MIN_SPHERES spheres, 2 always BVH
@@ -1371,6 +1383,7 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.bvh_nodes = ctx->bvh_nodes.p;
     s.bvh_sph = ctx->bvh_sph.p;
     s.bvh_idx = ctx->bvh_idx.p;
+    s.bvh_skips = ctx->bvh_skips.p;
     s.bvh_node_count = use_bvh ? ctx->bvh_node_count : 0;
     for (int k = 0; k < 3; k++) { s.bvh_lo[k] = ctx->bvh_lo[k]; s.bvh_hi[k] = ctx->bvh_hi[k]; }
     s.bvh_rmax = ctx->bvh_rmax;
@@ -1674,6 +1687,7 @@ void rt_destroy(rt_context *ctx) {
     ctx->bvh_nodes.release();
     ctx->bvh_sph.release();
     ctx->bvh_idx.release();
+    ctx->bvh_skips.release();
     for (int i = 0; i < rt_context::EV_RING; i++)
         for (int k = 0; k < 3; k++)
             if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
@@ -1803,7 +1817,7 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (all_bvh && !jobs.empty() && jobs.size() < (1u << 16)) HIP_TRY(ctx, ctx->walk_jobs.upload(jobs.data(), jobs.size()));
     }
     ctx->bvh_node_count = 0;
-    if (d->sphere_count > 0 && d->sphere_count < (1u << 26)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
+    if (d->sphere_count > 0 && d->sphere_count < (1u << 25)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
         bool finite = true;
         for (uint32_t i = 0; i < d->sphere_count && finite; i++)
             finite = std::isfinite(d->spheres[i].pos.x) && std::isfinite(d->spheres[i].pos.y) &&
@@ -1814,10 +1828,19 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
             bb.order.resize(d->sphere_count);
             for (uint32_t i = 0; i < d->sphere_count; i++) bb.order[i] = i;
             bb.build(0, d->sphere_count);
-            HIP_TRY(ctx, ctx->bvh_nodes.upload(bb.nodes.data(), bb.nodes.size()));
+            {   // device layout: 32-byte boxes, the skip links in an array of their own
+                std::vector<float4> boxes(bb.nodes.size() / 2);
+                std::vector<uint32_t> sk(bb.nodes.size() * 2);
+                for (size_t n = 0; n < bb.nodes.size() / 4; n++) {
+                    boxes[2 * n] = bb.nodes[4 * n]; boxes[2 * n + 1] = bb.nodes[4 * n + 1];
+                    memcpy(&sk[8 * n], &bb.nodes[4 * n + 2], 32);
+                }
+                HIP_TRY(ctx, ctx->bvh_nodes.upload(boxes.data(), boxes.size()));
+                HIP_TRY(ctx, ctx->bvh_skips.upload(sk.data(), sk.size()));
+            }
             HIP_TRY(ctx, ctx->bvh_sph.upload(bb.leaf_sph.data(), bb.leaf_sph.size()));
             HIP_TRY(ctx, ctx->bvh_idx.upload(bb.leaf_idx.data(), bb.leaf_idx.size()));
-            ctx->bvh_node_count = (uint32_t)(bb.nodes.size() / 2);
+            ctx->bvh_node_count = (uint32_t)(bb.nodes.size() / 4);
             ctx->bvh_rmax = 0;
             for (int k = 0; k < 3; k++) { ctx->bvh_lo[k] = INFINITY; ctx->bvh_hi[k] = -INFINITY; }
             for (uint32_t i = 0; i < d->sphere_count; i++) {
@@ -2061,48 +2084,61 @@ extern "C++" {
 namespace {
 struct BvhWalkStats { uint64_t nodes = 0, leaves = 0, prims = 0, max_depth = 0; };
 
-// walk a tree the way the kernels do (three-state stackless walk, every box "hit", a fixed
-// direction octant) and check the links; stride = float4 per node; returns "" or an error
-std::string host_walk(const std::vector<float4> &nodes, uint32_t stride, uint32_t root, uint32_t far_first,
-                      std::vector<uint32_t> &leaf_visits, BvhWalkStats &st) {
-    enum { FROM_PARENT, FROM_SIBLING, FROM_CHILD };
-    uint32_t n_nodes = (uint32_t)(nodes.size() / stride), cur = root;
-    int state = FROM_PARENT;
-    for (uint64_t guard = 0;; guard++) {
-        if (guard > 3ull * n_nodes + 8) return "walk does not terminate";
+// walk the sphere tree the way the kernel does for direction octant `oct` with every box "hit": nearer child
+// after an inner node, the octant's skip link after a leaf
+std::string host_walk_octant(const std::vector<float4> &nodes, uint32_t oct, std::vector<uint32_t> &leaf_visits, BvhWalkStats &st) {
+    uint32_t n_nodes = (uint32_t)(nodes.size() / 4), cur = BVH_ROOT;
+    for (uint64_t guard = 0; cur != BVH_END; guard++) {
+        if (guard > (uint64_t)n_nodes + 8) return "walk does not terminate";
         if (cur >= n_nodes) return "node index out of range";
-        uint32_t A, B;
-        memcpy(&A, &nodes[(size_t)stride * cur].w, 4);
-        memcpy(&B, &nodes[(size_t)stride * cur + 1].w, 4);
-        uint32_t parent = A & 0x0FFFFFFFu, sibling = (cur & 1u) ? cur + 1u : cur - 1u;
-        if (state == FROM_CHILD) {
-            if (cur == root) return "";
-            uint32_t pA, pB;
-            memcpy(&pA, &nodes[(size_t)stride * parent].w, 4);
-            memcpy(&pB, &nodes[(size_t)stride * parent + 1].w, 4);
-            uint32_t pnear = pB + ((far_first >> ((pA >> 28) & 3u)) & 1u);
-            if (cur == pnear) { cur = sibling; state = FROM_SIBLING; } else cur = parent;
-            continue;
-        }
+        uint32_t A, B, sk[8];
+        memcpy(&A, &nodes[4 * (size_t)cur].w, 4);
+        memcpy(&B, &nodes[4 * (size_t)cur + 1].w, 4);
+        memcpy(sk, &nodes[4 * (size_t)cur + 2], 32);
         st.nodes++;
-        bool leaf = (B & 0x80000000u) != 0;
-        if (leaf) {
+        if (B & 0x80000000u) {
             uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
             st.leaves++;
             for (uint32_t k = 0; k < cnt; k++) {
                 if (first + k >= leaf_visits.size()) return "leaf slot out of range";
                 leaf_visits[first + k]++;
             }
-        }
-        if (!leaf) {
+            cur = sk[oct];
+        } else {
             if (((A >> 28) & 3u) > 2) return "bad split axis";
-            if (!(B & 1u)) return "left child at an even index";
-            cur = B + ((far_first >> ((A >> 28) & 3u)) & 1u);
-            state = FROM_PARENT;
-        } else if (cur == root) return "";
-        else if (state == FROM_PARENT) { cur = sibling; state = FROM_SIBLING; }
-        else { cur = parent; state = FROM_CHILD; }
+            if (B & 1u) return "left child at an odd index";
+            cur = B + ((oct >> ((A >> 28) & 3u)) & 1u);
+        }
     }
+    return "";
+}
+
+// recursive structural check of the sphere tree: child boxes inside the parent's, the eight skip links, depth
+std::string host_check_sphere_tree(const std::vector<float4> &nodes, uint32_t me, uint32_t parent, const uint32_t skip[8],
+                                   bool is_root, uint32_t depth, BvhWalkStats &st) {
+    const float4 &lo = nodes[4 * (size_t)me], &hi = nodes[4 * (size_t)me + 1];
+    uint32_t A, B, sk[8];
+    memcpy(&A, &lo.w, 4);
+    memcpy(&B, &hi.w, 4);
+    memcpy(sk, &nodes[4 * (size_t)me + 2], 32);
+    for (int o = 0; o < 8; o++) if (sk[o] != skip[o]) return "wrong skip link";
+    st.max_depth = std::max<uint64_t>(st.max_depth, depth);
+    if (depth > 60) return "tree deeper than 60 levels";
+    if (!is_root) {
+        const float4 &plo = nodes[4 * (size_t)parent], &phi = nodes[4 * (size_t)parent + 1];
+        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
+            return "child box not inside its parent's";
+    }
+    if (B & 0x80000000u) return "";
+    uint32_t ax = (A >> 28) & 3u, sl[8], sr[8];
+    for (uint32_t o = 0; o < 8; o++) {
+        bool right_first = ((o >> ax) & 1u) != 0;
+        sl[o] = right_first ? skip[o] : B + 1u;
+        sr[o] = right_first ? B : skip[o];
+    }
+    std::string e = host_check_sphere_tree(nodes, B, me, sl, false, depth + 1, st);
+    if (e.empty()) e = host_check_sphere_tree(nodes, B + 1u, me, sr, false, depth + 1, st);
+    return e;
 }
 
 // the mesh trees are threaded (pt_mesh_bvh.hpp): follow "left child after an inner node, skip link after a leaf"
@@ -2146,33 +2182,15 @@ std::string host_check_threaded(const std::vector<float4> &nodes, uint32_t me, u
             return "child box not inside its parent's";
     }
     if (B & 0x80000000u) return "";
-    if (!(B & 1u)) return "left child at an even index";
-    std::string e = host_check_threaded(nodes, B, me, B + 1u, false, depth + 1, st);
-    if (e.empty()) e = host_check_threaded(nodes, B + 1u, me, skip, false, depth + 1, st);
+    uint32_t right;   // = the left child's skip link
+    memcpy(&right, &nodes[4 * (size_t)B].w, 4);
+    right &= 0x0FFFFFFFu;
+    if (right >= nodes.size() / 4) return "left child's skip link out of range";
+    std::string e = host_check_threaded(nodes, B, me, right, false, depth + 1, st);
+    if (e.empty()) e = host_check_threaded(nodes, right, me, skip, false, depth + 1, st);
     return e;
 }
 
-// recursive structural check: child boxes inside the parent's, parent links, depth
-std::string host_check_tree(const std::vector<float4> &nodes, uint32_t stride, uint32_t me, uint32_t parent, bool is_root,
-                            uint32_t depth, BvhWalkStats &st) {
-    const float4 &lo = nodes[(size_t)stride * me], &hi = nodes[(size_t)stride * me + 1];
-    uint32_t A, B;
-    memcpy(&A, &lo.w, 4);
-    memcpy(&B, &hi.w, 4);
-    if ((A & 0x0FFFFFFFu) != parent) return "wrong parent link";
-    st.max_depth = std::max<uint64_t>(st.max_depth, depth);
-    if (!is_root) {
-        const float4 &plo = nodes[(size_t)stride * parent], &phi = nodes[(size_t)stride * parent + 1];
-        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
-            return "child box not inside its parent's";
-    }
-    if (B & 0x80000000u) return "";
-    for (uint32_t k = 0; k < 2; k++) {
-        std::string e = host_check_tree(nodes, stride, B + k, me, false, depth + 1, st);
-        if (!e.empty()) return e;
-    }
-    return "";
-}
 }  // namespace
 }  // extern "C++"
 
@@ -2191,12 +2209,13 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
         for (uint32_t i = 0; i < d->sphere_count; i++) bb.order[i] = i;
         bb.build(0, d->sphere_count);
         BvhWalkStats st;
-        std::string e = host_check_tree(bb.nodes, 2, 0, 0, true, 0, st);
+        const uint32_t end[8] = {BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END, BVH_END};
+        std::string e = host_check_sphere_tree(bb.nodes, BVH_ROOT, BVH_ROOT, end, true, 0, st);
         if (!e.empty()) return bad("sphere bvh: " + e);
         for (uint32_t oct = 0; oct < 8; oct++) {
             std::vector<uint32_t> visits(bb.leaf_idx.size(), 0);
             BvhWalkStats w;
-            e = host_walk(bb.nodes, 2, 0, oct, visits, w);
+            e = host_walk_octant(bb.nodes, oct, visits, w);
             if (!e.empty()) return bad("sphere bvh: " + e);
             for (uint32_t v : visits) if (v != 1) return bad("sphere bvh: a leaf slot is not visited exactly once");
             st.nodes = w.nodes; st.leaves = w.leaves;
@@ -2205,14 +2224,14 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
         if (bb.leaf_idx.size() != d->sphere_count) return bad("sphere bvh: leaf slot count != sphere count");
         for (uint32_t i : bb.leaf_idx) { if (i >= d->sphere_count || seen[i]++) return bad("sphere bvh: sphere missing or duplicated"); }
         // every sphere inside its leaf's box
-        for (uint32_t n = 0; n < bb.nodes.size() / 2; n++) {
+        for (uint32_t n = BVH_ROOT; n < bb.nodes.size() / 4; n++) {
             uint32_t B;
-            memcpy(&B, &bb.nodes[2 * n + 1].w, 4);
+            memcpy(&B, &bb.nodes[4 * (size_t)n + 1].w, 4);
             if (!(B & 0x80000000u)) continue;
             uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
             for (uint32_t k = 0; k < cnt; k++) {
                 const rt_sphere &sp = d->spheres[bb.leaf_idx[first + k]];
-                const float4 &lo = bb.nodes[2 * n], &hi = bb.nodes[2 * n + 1];
+                const float4 &lo = bb.nodes[4 * (size_t)n], &hi = bb.nodes[4 * (size_t)n + 1];
                 float r = std::fabs(sp.r);
                 if (sp.pos.x - r < lo.x || sp.pos.y - r < lo.y || sp.pos.z - r < lo.z || sp.pos.x + r > hi.x ||
                     sp.pos.y + r > hi.y || sp.pos.z + r > hi.z)
@@ -2259,9 +2278,11 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
                 uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
                 for (uint32_t k = 0; k < cnt; k++) faces.push_back(lidx[first + k]);
             } else {
+                uint32_t right;
+                memcpy(&right, &nodes[4 * (size_t)B].w, 4);
                 for (uint32_t k = 0; k < 2; k++) {
                     std::vector<uint32_t> sub;
-                    std::string er = collect(B + k, sub);
+                    std::string er = collect(k ? (right & 0x0FFFFFFFu) : B, sub);
                     if (!er.empty()) return er;
                     faces.insert(faces.end(), sub.begin(), sub.end());
                 }
