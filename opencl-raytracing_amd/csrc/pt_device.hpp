@@ -449,11 +449,12 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
       if (cur != PT_BVH_END && !at_leaf) {
         const float4 *nd2 = at32(sc.bvh_nodes, cur << 5);
         float4 a = nd2[0], b = nd2[1];
-        const uint32_t skip = *at32(sc.bvh_skips, (cur << 5) + (oct << 2));   // (its own array: 32-byte boxes keep a sibling pair in one 64-byte stretch — C4 at 16 spp 132.3 → 117.8 ms against links inside a 64-byte node)
+        uint32_t skip = *at32(sc.bvh_skips, (cur << 5) + (oct << 2));   // (its own array: 32-byte boxes keep a sibling pair in one 64-byte stretch — C4 at 16 spp 132.3 → 117.8 ms against links inside a 64-byte node)
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         // (both header words are pinned here: left to itself the compiler fetches the box as two 12-byte loads and
         // the header words only after a hit, one after the other — two more trips to memory on the way down)
-        asm volatile("" : "+v"(A), "+v"(B));
+        // (not `volatile`: that would also stop the hoisting and scalarisation of every other load of the kernel)
+        asm("" : "+v"(A), "+v"(B), "+v"(skip));
         if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
         // slab test against the inflated box (fminf/fmaxf drop the NaN of 0·inf)
         float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));

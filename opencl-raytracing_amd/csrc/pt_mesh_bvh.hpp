@@ -197,7 +197,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uin
             float4 a = nd[0], b = nd[1], cn = nd[2], ex = nd[3];
             // (pinned: left to itself the compiler fetches cn as 12 bytes and cn.w only after the index test has
             // passed — a second trip to memory in every node test)
-            asm volatile("" : "+v"(cn.w), "+v"(a.w), "+v"(b.w));
+            asm("" : "+v"(cn.w), "+v"(a.w), "+v"(b.w));
             const uint32_t B = __float_as_uint(b.w);
             if (mesh_node_miss<MODE>(r, k, a, b, cn, ex, best_face, dbg)) cur = __float_as_uint(a.w) & PT_MESH_END;
             else if (B & 0x80000000u) cur |= PT_MESH_PARKED;
