@@ -489,8 +489,10 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                 uint32_t first = leaf_b & 0x0FFFFFFFu, cnt = (leaf_b >> 28) & 7u;
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
-                    float t = sphere_t(r, *at32(sc.bvh_sph, (first + k) << 4));
+                    float4 sp = *at32(sc.bvh_sph, (first + k) << 4);
                     uint32_t idx = *at32(sc.bvh_idx, (first + k) << 2);
+                    asm("" : "+v"(idx), "+v"(sp.x));   // (fetched together; the index is needed after a hit only)
+                    float t = sphere_t(r, sp);
                     if (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK))) {
                         best_t = t;
                         best_id = K_SPHERE | idx;

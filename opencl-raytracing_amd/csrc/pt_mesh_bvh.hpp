@@ -216,10 +216,12 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uin
                 uint32_t A = __float_as_uint(nd[0].w), B = __float_as_uint(nd[1].w);
                 uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
                 for (uint32_t j = 0; j < cnt; j++) {
+                    // (index and record fetched together — one trip to memory per face, not two)
                     uint32_t idx = *at32(sc.mbvh_face_idx, (first + j) << 2);
-                    if (idx >= best_face) continue;
                     const float4 *fq = at32(sc.mbvh_faces, (first + j) * 48u);
                     float4 q0 = fq[0], q1 = fq[1], q2 = fq[2];
+                    asm("" : "+v"(idx), "+v"(q0.x), "+v"(q1.x), "+v"(q2.x));
+                    if (idx >= best_face) continue;
 #ifndef PT_MESH_STAT
                     if (dbg) dbg->c[CN_DBG_BVH_TESTS]++;
 #endif
