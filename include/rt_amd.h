@@ -330,8 +330,8 @@ int rt_get_counters(rt_context *ctx, rt_counters *out);
 
 /* Host-only self-check (no device, no context): builds the sphere BVH and the per-mesh BVHs
  * exactly as rt_set_scene does and verifies their invariants — every primitive in exactly one
- * leaf and inside its boxes, child boxes inside parent boxes, parent / sibling / split-axis
- * links, the stackless walk visiting every leaf exactly once in all eight direction octants,
+ * leaf and inside its boxes, child boxes inside parent boxes, split axes and skip links (both
+ * walks are threaded), the walk visiting every leaf exactly once in all eight direction octants,
  * smallest-face indices, normal cones, edge bounds.  stats = {sphere nodes, sphere leaves,
  * sphere depth, mesh nodes, mesh leaves, mesh depth, meshes with a BVH, 0}. */
 int rt_debug_check_accel(const rt_scene_desc *scene, uint64_t stats[8], char *err, size_t err_len);

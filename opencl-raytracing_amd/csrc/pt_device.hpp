@@ -402,11 +402,10 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 //   * candidates are compared by (t, original index), so ties resolve as in the
 //     reference's in-order scan with strict '<';
 //   * rays whose direction is far from unit length (or NaN) take the brute-force loop.
-// Traversal is stackless and ORDERED (near child first, so the best-t bound prunes the far
-// side): nodes carry their parent, siblings are adjacent (left child at an odd index), and a
-// three-state walk (from parent / from sibling / from child) replaces the stack.
-//   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = parent | split_axis << 28;
-//   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
+// Traversal is ORDERED (near child first, so the best-t bound prunes the far side) and keeps neither a
+// stack nor a way back up: the tree is threaded per direction octant (see hit_spheres_bvh).
+//   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = split_axis << 28;  siblings adjacent, the left one at an even index;
+//   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere;  bvh_skips[8·node + octant] = skip link.
 // base + a 32-BIT byte offset: the compiler then uses the scalar-base form of the global load (one 32-bit shift
 // instead of 64-bit address arithmetic per access).  The host keeps every BVH array below 4 GiB (rt_set_scene).
 template <class T>

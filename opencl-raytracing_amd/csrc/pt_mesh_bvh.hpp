@@ -56,9 +56,6 @@
 #ifndef PT_MESH_SLAB_SCALE
 #define PT_MESH_SLAB_SCALE 1.0f  // test hook: < 1 must break tests/test_gpu_properties.py::test_mesh_bvh_grazing_rays
 #endif
-#ifndef PT_MESH_HOPS
-#define PT_MESH_HOPS 1  // A/B on C5 at 16 spp: 1 → 97.9 ms, 2 → 98.8, 3 → 107 (and 110.8 with a hop per step)
-#endif
 #ifndef PT_MESH_SLAB_SIN
 #define PT_MESH_SLAB_SIN 0.5f
 #endif
@@ -79,7 +76,7 @@
 // MeshWalk is the walk's whole position; mesh_bvh_steps advances it by at most max_steps nodes and returns true once
 // the tree is exhausted — a kernel can interleave walks of different lengths with other work (pt_samples_w).
 #ifdef PT_WSTAT  // diagnostic build (tools/wstat.py): wave-level lane census of the walk, never timed
-struct WalkStat { unsigned long long steps, node_lanes, hop_lanes, leaf_runs, leaf_lanes, idle_lanes; };
+struct WalkStat { unsigned long long steps, node_lanes, leaf_runs, leaf_lanes, idle_lanes; };
 #define PT_WSTAT_ARG , WalkStat *ws = nullptr
 #else
 #define PT_WSTAT_ARG

@@ -565,8 +565,8 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 // to hundreds: run in place, a wave executes the walk loop until its slowest lane is through — rocprofv3
 // counted 9 of 64 lanes active per VALU instruction on C5.  Here every lane is a small state machine
 //     0 material interaction + spheres/planes/lenses → 1 walking → 2 winner's record, material, next bounce
-// and each loop iteration advances EVERY walking lane by at most PT_WALK_STEPS nodes (the stackless walk's
-// whole position is (node, state)), while lanes in the cheap states 0 and 2 pass through them: lanes start
+// and each loop iteration advances EVERY walking lane by at most PT_WALK_STEPS nodes (the threaded walk's
+// whole position is one node index), while lanes in the cheap states 0 and 2 pass through them: lanes start
 // and finish walks at different times, so the walk loop always has many lanes in it.  Same arithmetic per
 // sample as pt_samples_q, same slots, same summation order: bit-identical.
 #ifndef PT_WALK_STEPS
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     float nb_u = 0.0f, nb_v = 0.0f;
 
 #ifdef PT_WSTAT
-    WalkStat ws = {0, 0, 0, 0, 0, 0};
+    WalkStat ws = {0, 0, 0, 0, 0};
     unsigned long long it_n = 0, it_active = 0, it_p0 = 0, it_p1 = 0, it_p2 = 0, it_walk_calls = 0;
 #endif
     // every iteration takes samples off the queue, or moves every active lane on (a bounce, or up to
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     }
 #ifdef PT_WSTAT
     if (lane == 0 && npix) {
-        unsigned long long v[12] = {it_n, it_active, it_p0, it_p1, it_p2, it_walk_calls, ws.steps, ws.node_lanes, ws.hop_lanes,
+        unsigned long long v[12] = {it_n, it_active, it_p0, it_p1, it_p2, it_walk_calls, ws.steps, ws.node_lanes, 0ull,
                                     ws.leaf_runs, ws.leaf_lanes, ws.idle_lanes};
         for (int k = 0; k < 12; k++) atomicAdd(&wstat[k], v[k]);
     }
@@ -1072,8 +1072,9 @@ void make_table(uint64_t seed, float *out) {
 
 // Sphere BVH (see hit_spheres_bvh): binned surface-area-heuristic splits (16 bins per axis over the
 // centroids; median split when no bin boundary separates them), leaves of <= 4 spheres; children
-// are allocated in adjacent pairs (left at an odd index, lower coordinates along the split axis),
-// every node records its parent and split axis for the stackless ordered traversal.
+// are allocated in adjacent pairs (left at an even index, lower coordinates along the split axis),
+// every node records its split axis and, per direction octant, the node that follows its subtree in the
+// near-before-far order of that octant (the walk is threaded: no stack, no way back up).
 #ifndef SPHERE_BVH_LEAF
 #define SPHERE_BVH_LEAF 4  // spheres per leaf (<= 7)
 #endif
@@ -1817,7 +1818,7 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (all_bvh && !jobs.empty() && jobs.size() < (1u << 16)) HIP_TRY(ctx, ctx->walk_jobs.upload(jobs.data(), jobs.size()));
     }
     ctx->bvh_node_count = 0;
-    if (d->sphere_count > 0 && d->sphere_count < (1u << 25)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
+    if (d->sphere_count > 0 && d->sphere_count < (1u << 26)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
         bool finite = true;
         for (uint32_t i = 0; i < d->sphere_count && finite; i++)
             finite = std::isfinite(d->spheres[i].pos.x) && std::isfinite(d->spheres[i].pos.y) &&
@@ -2501,7 +2502,7 @@ int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]) {
         unsigned long long v[12];
         if (hipMemcpy(v, ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8, sizeof v, hipMemcpyDeviceToHost) == hipSuccess) {
             const char *names[12] = {"outer iterations", "active lanes", "phase-0 lanes", "phase-1 lanes", "phase-2 lanes", "walk slices",
-                                     "walk steps", "node-test lanes", "hop lanes", "leaf phases", "leaf lanes", "finished (idle) lanes"};
+                                     "walk steps", "node-test lanes", "(unused)", "leaf phases", "leaf lanes", "finished (idle) lanes"};
             for (int k = 0; k < 12; k++) fprintf(stderr, "[wstat] %-24s %llu\n", names[k], v[k]);
             (void)hipMemset(ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8, 0, sizeof v);
         }

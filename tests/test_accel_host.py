@@ -1,6 +1,6 @@
 """CPU: the acceleration structures are host logic (built at rt_set_scene) — their invariants
 are checked without a device through rt_debug_check_accel: every primitive in exactly one leaf and
-inside its boxes, nested boxes, parent/sibling/axis links, the kernels' stackless walk visiting
+inside its boxes, nested boxes, split axes and skip links, the kernels' threaded walk visiting
 every leaf exactly once in all eight direction octants, smallest-face indices, normal cones."""
 import numpy as np
 import pytest

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/wstat.py — lane census of pt_samples_w (GPU box; needs the diagnostic build
 `tools/build_variant.sh wstat -DPT_WSTAT=1`): how many lanes sit in which phase per outer iteration, and inside the
-mesh walk how many lanes test a node / hop / wait per step.  Prints the raw counters ([wstat] lines on stderr)."""
+mesh walk how many lanes test a node / wait per step.  Prints the raw counters ([wstat] lines on stderr)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import opencl_raytracing_amd as rt
