@@ -14,6 +14,18 @@
 #define MESH_BVH_LEAF 2  // faces per leaf (<= 7); A/B on C5: 1 → 249 ms, 2 → 227 ms, 4 → 280 ms
 #endif
 
+// A node's box is stored as centre and half extent (the slab tests then need no min / max: near = (c − o)·inv − (h + m)·|inv|):
+// c = the rounded midpoint, h = the larger distance from c to the two bounds, rounded UP — [c − h, c + h] contains [lo, hi].
+inline void bvh_centre_half(const float lo[3], const float hi[3], float c[3], float h[3]) {
+    for (int k = 0; k < 3; k++) {
+        c[k] = (float)(((double)lo[k] + (double)hi[k]) * 0.5);
+        double hd = std::fmax((double)hi[k] - (double)c[k], (double)c[k] - (double)lo[k]);
+        float hf = (float)hd;
+        if ((double)hf < hd) hf = std::nextafter(hf, INFINITY);
+        h[k] = std::nextafter(hf, INFINITY);   // one more ulp: c − h and c + h are themselves rounded on the device
+    }
+}
+
 struct MeshBvhBuilder {
     // inputs: the mesh's face records (3 float4 per face: A, e1, e2, n as DeviceScene::faces)
     const float4 *rec = nullptr;
@@ -182,8 +194,10 @@ struct MeshBvhBuilder {
             fill(left + 1, skip, mid, e, depth + 1u);
         }
         float4 *nd = nodes->data() + 4 * (size_t)me;
-        nd[0] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
-        nd[1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
+        float bc[3], bh[3];
+        bvh_centre_half(nlo, nhi, bc, bh);
+        nd[0] = make_float4(bc[0], bc[1], bc[2], 0.0f);
+        nd[1] = make_float4(bh[0], bh[1], bh[2], 0.0f);
         nd[2] = make_float4((float)ax[0], (float)ax[1], (float)ax[2], (float)cos_a);
         nd[3] = make_float4((float)sin_a, 0.0f, emax, q);
         memcpy(&nd[0].w, &A, 4);

@@ -170,7 +170,7 @@ struct DeviceScene {
     const uint32_t *mbvh_face_idx;  // their face index inside the mesh
     const uint32_t *mesh_bvh_root;  // per mesh
     // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
-    const float4 *bvh_nodes;   // 2 float4 per node: (lo.xyz, split axis << 28), (hi.xyz, left child | leaf)
+    const float4 *bvh_nodes;   // 2 float4 per node: (box centre.xyz, split axis << 28), (box half extent.xyz, left child | leaf)
     const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
     const uint32_t *bvh_idx;   // their original indices
     const uint32_t *bvh_skips; // 8 per node: where a ray of direction octant o goes after the node's subtree (hit_spheres_bvh)
@@ -404,7 +404,7 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 //   * rays whose direction is far from unit length (or NaN) take the brute-force loop.
 // Traversal is ORDERED (near child first, so the best-t bound prunes the far side) and keeps neither a
 // stack nor a way back up: the tree is threaded per direction octant (see hit_spheres_bvh).
-//   node = 2 float4: (lo.xyz, A), (hi.xyz, B);  A = split_axis << 28;  siblings adjacent, the left one at an even index;
+//   node = 2 float4: (box centre.xyz, A), (box half extent.xyz, B);  A = split_axis << 28;  siblings adjacent, the left one at an even index;
 //   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere;  bvh_skips[8·node + octant] = skip link.
 // base + a 32-BIT byte offset: the compiler then uses the scalar-base form of the global load (one 32-bit shift
 // instead of 64-bit address arithmetic per access).  The host keeps every BVH array below 4 GiB (rt_set_scene).
@@ -429,7 +429,6 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     float k_ray = __builtin_amdgcn_sqrtf(2.0f * c_ray) * 1.02f;   // margin per unit of distance to the node
     float o_max = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
     V3 inv = cull_inverse(r.d);
-    const V3 noi = mk(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));   // slab test: t = fma(plane, inv, -o·inv)
     // the ray's direction octant: bit k set → along axis k the RIGHT child (higher coordinates) is the nearer one
     const uint32_t oct = (r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u);
 
@@ -456,18 +455,17 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
         asm("" : "+v"(A), "+v"(B), "+v"(skip));
         if (COUNT) cn->c[CN_DBG_BVH_NODES]++;
         // slab test against the inflated box (fminf/fmaxf drop the NaN of 0·inf)
-        float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
-        float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
-        float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
+        // (a = the box's centre, b = its half extent: the farthest corner, and below the slab distances, without min / max)
+        const V3 dc = mk(a.x - r.o.x, a.y - r.o.y, a.z - r.o.z);
+        float fx = fabsf(dc.x) + b.x, fy = fabsf(dc.y) + b.y, fz = fabsf(dc.z) + b.z;
         // (culling arithmetic, not the reference's: fused multiply-adds — fewer instructions, smaller rounding)
         float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;  // approximate sqrt, rounded up
         float m = __builtin_fmaf(k_ray, dfar, __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f));
-        float t1 = __builtin_fmaf(a.x - m, inv.x, noi.x), t2 = __builtin_fmaf(b.x + m, inv.x, noi.x);
-        float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
-        t1 = __builtin_fmaf(a.y - m, inv.y, noi.y); t2 = __builtin_fmaf(b.y + m, inv.y, noi.y);
-        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-        t1 = __builtin_fmaf(a.z - m, inv.z, noi.z); t2 = __builtin_fmaf(b.z + m, inv.z, noi.z);
-        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        // per axis the line is inside the inflated slab for t in [tc − te, tc + te], tc = (c − o)/d, te = (h + m)/|d|
+        // (the rounding of this form, 2^-24·(3·dfar + o_max) in units of distance, is 50 × below the slack in m)
+        float tcx = dc.x * inv.x, tcy = dc.y * inv.y, tcz = dc.z * inv.z;
+        float tex = (b.x + m) * fabsf(inv.x), tey = (b.y + m) * fabsf(inv.y), tez = (b.z + m) * fabsf(inv.z);
+        float tmin = fmaxf(fmaxf(tcx - tex, tcy - tey), tcz - tez), tmax = fminf(fminf(tcx + tex, tcy + tey), tcz + tez);
         bool miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f   // the line misses the box
                     || tmax < -1.0e-2f                                             // box entirely behind the origin
                     || tmin > __builtin_fmaf(best_t, 1.00001f, 1.0e-2f);           // box entirely beyond the best hit

@@ -36,7 +36,7 @@
 // tests/test_gpu_properties.py::test_mesh_bvh_keeps_faces_accepted_far_from_the_ray drives rays the
 // reference accepts 2–5 edge lengths away from the face through this walk.
 //
-// Node = 4 float4: (lo.xyz, A) (hi.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
+// Node = 4 float4: (box centre.xyz, A) (box half extent.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
 //   A = skip link (the node after this subtree; PT_MESH_END = none);  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
 // (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
 #pragma once
@@ -133,21 +133,20 @@ PT_DEV bool mesh_node_miss(const Ray &r, const MeshCull &k, float4 a, float4 b, 
         if (backside) miss = true;
         bool capped = ex.z * ex.z * dlen <= 0.04f;              // the epsilon test bounds the displacement
         if (!backside && (steep || capped)) {
-            float fx = fmaxf(fabsf(a.x - r.o.x), fabsf(b.x - r.o.x));
-            float fy = fmaxf(fabsf(a.y - r.o.y), fabsf(b.y - r.o.y));
-            float fz = fmaxf(fabsf(a.z - r.o.z), fabsf(b.z - r.o.z));
+            // (a = the box's centre, b = its half extent: the farthest corner, and below the slab distances, without min / max)
+            const V3 dc = mk(a.x - r.o.x, a.y - r.o.y, a.z - r.o.z);
+            float fx = fabsf(dc.x) + b.x, fy = fabsf(dc.y) + b.y, fz = fabsf(dc.z) + b.z;
             float dfar = __builtin_amdgcn_sqrtf(__builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx))) * 1.001f;
             float reach = __builtin_fmaf(2.0f, ex.z, dfar);
             // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
             float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
             float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
             float m = fminf(m_steep, m_cap) + __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f);
-            float t1 = (a.x - m - r.o.x) * inv.x, t2 = (b.x + m - r.o.x) * inv.x;
-            float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
-            t1 = (a.y - m - r.o.y) * inv.y; t2 = (b.y + m - r.o.y) * inv.y;
-            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-            t1 = (a.z - m - r.o.z) * inv.z; t2 = (b.z + m - r.o.z) * inv.z;
-            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+            // per axis the line is inside the inflated slab for t in [tc − te, tc + te], tc = (c − o)/d, te = (h + m)/|d|
+            // (the rounding of this form, 2^-24·(3·dfar + o_max) in units of distance, is 50 × below the slack in m)
+            float tcx = dc.x * inv.x, tcy = dc.y * inv.y, tcz = dc.z * inv.z;
+            float tex = (b.x + m) * fabsf(inv.x), tey = (b.y + m) * fabsf(inv.y), tez = (b.z + m) * fabsf(inv.z);
+            float tmin = fmaxf(fmaxf(tcx - tex, tcy - tey), tcz - tez), tmax = fminf(fminf(tcx + tex, tcy + tey), tcz + tez);
             // the LINE misses the inflated box, or the box lies wholly behind / beyond the range of t
             miss = tmin > __builtin_fmaf(fabsf(tmax), 1.0e-5f, tmax) + 1.0e-4f || tmax < -(m + 1.0f) ||
                    tmin > RT_MAX_DISTANCE * 1.001f + m + 1.0f;
@@ -159,10 +158,8 @@ PT_DEV bool mesh_node_miss(const Ray &r, const MeshCull &k, float4 a, float4 b, 
                 // cone axis perpendicular to d every face of the subtree is thin: an edge e is
                 // perpendicular to its normal, so |e . n'| <= |e| (sin alpha + |cos psi|) / sin psi.
                 V3 np = (xyz(cn) - dh * x) * __builtin_amdgcn_rcpf(sb);   // |x| <= sin(alpha) + tau here (sb > 0.5)
-                float hx = 0.5f * (b.x - a.x), hy = 0.5f * (b.y - a.y), hz = 0.5f * (b.z - a.z);
-                float rn = fabsf(np.x) * hx + fabsf(np.y) * hy + fabsf(np.z) * hz;
-                float dist = (r.o.x - 0.5f * (a.x + b.x)) * np.x + (r.o.y - 0.5f * (a.y + b.y)) * np.y +
-                             (r.o.z - 0.5f * (a.z + b.z)) * np.z;
+                float rn = fabsf(np.x) * b.x + fabsf(np.y) * b.y + fabsf(np.z) * b.z;
+                float dist = dc.x * np.x + dc.y * np.y + dc.z * np.z;   // (its sign is not needed)
                 float mn = PT_MESH_SLAB_SCALE * m_cap * (ex.x + fabsf(x) + 2.0e-4f) * (__builtin_amdgcn_rcpf(sb) * 1.000002f) +
                            1.0e-5f * (dfar + o_max) + 1.0e-5f;
                 if (fabsf(dist) > rn * 1.0001f + mn) miss = true;

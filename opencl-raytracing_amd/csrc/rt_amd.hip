@@ -1197,8 +1197,10 @@ struct BvhBuild {
             fill(left, skip_l, b, mid, depth + 1u);
             fill(left + 1, skip_r, mid, e, depth + 1u);
         }
-        nodes[4 * (size_t)me] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-        nodes[4 * (size_t)me + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        float bc[3], bh[3];
+        bvh_centre_half(lo, hi, bc, bh);
+        nodes[4 * (size_t)me] = make_float4(bc[0], bc[1], bc[2], 0.0f);
+        nodes[4 * (size_t)me + 1] = make_float4(bh[0], bh[1], bh[2], 0.0f);
         memcpy(&nodes[4 * (size_t)me].w, &A, 4);
         memcpy(&nodes[4 * (size_t)me + 1].w, &B, 4);
         memcpy(&nodes[4 * (size_t)me + 2], skip, 32);
@@ -2125,11 +2127,7 @@ std::string host_check_sphere_tree(const std::vector<float4> &nodes, uint32_t me
     for (int o = 0; o < 8; o++) if (sk[o] != skip[o]) return "wrong skip link";
     st.max_depth = std::max<uint64_t>(st.max_depth, depth);
     if (depth > 60) return "tree deeper than 60 levels";
-    if (!is_root) {
-        const float4 &plo = nodes[4 * (size_t)parent], &phi = nodes[4 * (size_t)parent + 1];
-        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
-            return "child box not inside its parent's";
-    }
+    (void)parent; (void)is_root;   // (boxes: every primitive is checked against the box of EVERY node above it, see rt_debug_check_accel)
     if (B & 0x80000000u) return "";
     uint32_t ax = (A >> 28) & 3u, sl[8], sr[8];
     for (uint32_t o = 0; o < 8; o++) {
@@ -2177,11 +2175,7 @@ std::string host_check_threaded(const std::vector<float4> &nodes, uint32_t me, u
     if ((A & 0x0FFFFFFFu) != skip) return "wrong skip link";
     st.max_depth = std::max<uint64_t>(st.max_depth, depth);
     if (depth > 60) return "tree deeper than 60 levels";
-    if (!is_root) {
-        const float4 &plo = nodes[4 * (size_t)parent], &phi = nodes[4 * (size_t)parent + 1];
-        if (lo.x < plo.x || lo.y < plo.y || lo.z < plo.z || hi.x > phi.x || hi.y > phi.y || hi.z > phi.z)
-            return "child box not inside its parent's";
-    }
+    (void)parent; (void)is_root;   // (boxes: every primitive is checked against the box of EVERY node above it, see rt_debug_check_accel)
     if (B & 0x80000000u) return "";
     uint32_t right;   // = the left child's skip link
     memcpy(&right, &nodes[4 * (size_t)B].w, 4);
@@ -2224,20 +2218,37 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
         std::vector<uint32_t> seen(d->sphere_count, 0);
         if (bb.leaf_idx.size() != d->sphere_count) return bad("sphere bvh: leaf slot count != sphere count");
         for (uint32_t i : bb.leaf_idx) { if (i >= d->sphere_count || seen[i]++) return bad("sphere bvh: sphere missing or duplicated"); }
-        // every sphere inside its leaf's box
-        for (uint32_t n = BVH_ROOT; n < bb.nodes.size() / 4; n++) {
+        // every sphere inside the box (centre ± half extent) of its leaf and of every node above it
+        std::function<std::string(uint32_t, std::vector<uint32_t> &)> gather = [&](uint32_t n, std::vector<uint32_t> &sph) -> std::string {
             uint32_t B;
             memcpy(&B, &bb.nodes[4 * (size_t)n + 1].w, 4);
-            if (!(B & 0x80000000u)) continue;
-            uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const rt_sphere &sp = d->spheres[bb.leaf_idx[first + k]];
-                const float4 &lo = bb.nodes[4 * (size_t)n], &hi = bb.nodes[4 * (size_t)n + 1];
-                float r = std::fabs(sp.r);
-                if (sp.pos.x - r < lo.x || sp.pos.y - r < lo.y || sp.pos.z - r < lo.z || sp.pos.x + r > hi.x ||
-                    sp.pos.y + r > hi.y || sp.pos.z + r > hi.z)
-                    return bad("sphere bvh: sphere outside its leaf box");
+            if (B & 0x80000000u) {
+                uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
+                for (uint32_t k = 0; k < cnt; k++) sph.push_back(bb.leaf_idx[first + k]);
+            } else {
+                for (uint32_t k = 0; k < 2; k++) {
+                    std::vector<uint32_t> sub;
+                    std::string er = gather(B + k, sub);
+                    if (!er.empty()) return er;
+                    sph.insert(sph.end(), sub.begin(), sub.end());
+                }
             }
+            const float4 &c = bb.nodes[4 * (size_t)n], &h = bb.nodes[4 * (size_t)n + 1];
+            for (uint32_t i : sph) {
+                const rt_sphere &sp = d->spheres[i];
+                const float r = std::fabs(sp.r), p[3] = {sp.pos.x, sp.pos.y, sp.pos.z};
+                for (int k = 0; k < 3; k++) {   // (the sphere's extent in binary32, as BvhBuild::bounds forms it)
+                    const double lo = (double)(&c.x)[k] - (double)(&h.x)[k], hi = (double)(&c.x)[k] + (double)(&h.x)[k];
+                    const float slo = p[k] - r, shi = p[k] + r;
+                    if ((double)slo < lo || (double)shi > hi) return std::string("sphere outside the box of a node above it");
+                }
+            }
+            return "";
+        };
+        {
+            std::vector<uint32_t> all;
+            e = gather(BVH_ROOT, all);
+            if (!e.empty()) return bad("sphere bvh: " + e);
         }
         stats[0] = st.nodes; stats[1] = st.leaves; stats[2] = st.max_depth;
     }
@@ -2296,8 +2307,8 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
                 true_min = std::min(true_min, f);
                 const float4 *q = mb.rec + 3 * (size_t)f;
                 double A[3] = {q[0].x, q[0].y, q[0].z}, e1[3] = {q[0].w, q[1].x, q[1].y}, e2[3] = {q[1].z, q[1].w, q[2].x};
-                for (int k = 0; k < 3; k++) {
-                    const float l = (&lo.x)[k], h = (&hi.x)[k];
+                for (int k = 0; k < 3; k++) {   // (lo, hi here: the node's centre and half extent)
+                    const double l = (double)(&lo.x)[k] - (double)(&hi.x)[k], h = (double)(&lo.x)[k] + (double)(&hi.x)[k];
                     double p[3] = {A[k], A[k] + e1[k], A[k] + e2[k]};
                     for (double v : p) if (v < l || v > h) return std::string("face outside its node box");
                 }
