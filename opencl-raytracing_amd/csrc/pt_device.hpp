@@ -170,10 +170,10 @@ struct DeviceScene {
     const uint32_t *mbvh_face_idx;  // their face index inside the mesh
     const uint32_t *mesh_bvh_root;  // per mesh
     // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
-    const float4 *bvh_nodes;   // 2 float4 per node: (box centre.xyz, split axis << 28), (box half extent.xyz, left child | leaf)
+    const float4 *bvh_nodes;   // 1 float4 per node: (box centre.xyz, left child | leaf)
     const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
     const uint32_t *bvh_idx;   // their original indices
-    const uint32_t *bvh_skips; // 8 per node: where a ray of direction octant o goes after the node's subtree (hit_spheres_bvh)
+    const float4 *bvh_links;   // 8 per node, one per direction octant o: (skip link | split axis << 28, box half extent.xyz) (hit_spheres_bvh)
     uint32_t bvh_node_count;
     float bvh_lo[3], bvh_hi[3];  // bounds of all sphere CENTRES
     float bvh_rmax;              // largest radius
@@ -404,8 +404,9 @@ PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis)
 //   * rays whose direction is far from unit length (or NaN) take the brute-force loop.
 // Traversal is ORDERED (near child first, so the best-t bound prunes the far side) and keeps neither a
 // stack nor a way back up: the tree is threaded per direction octant (see hit_spheres_bvh).
-//   node = 2 float4: (box centre.xyz, A), (box half extent.xyz, B);  A = split_axis << 28;  siblings adjacent, the left one at an even index;
-//   B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere;  bvh_skips[8·node + octant] = skip link.
+//   builder's node = 4 float4: (box centre.xyz, A), (box half extent.xyz, B), 8 skip links;  A = split_axis << 28;  siblings
+//   adjacent, the left one at an even index;  B = left child index, or for a leaf 0x80000000 | count << 28 | first sphere.
+//   device: bvh_nodes[node] = (centre, B), bvh_links[8·node + octant] = (skip link | A, half extent).
 // base + a 32-BIT byte offset: the compiler then uses the scalar-base form of the global load (one 32-bit shift
 // instead of 64-bit address arithmetic per access).  The host keeps every BVH array below 4 GiB (rt_set_scene).
 template <class T>
@@ -445,9 +446,18 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     uint32_t leaf_b = 0, leaf_skip = 0;
     for (uint32_t guard = 0; guard < sc.bvh_node_count + 8u; guard++) {  // every node is tested at most once
       if (cur != PT_BVH_END && !at_leaf) {
-        const float4 *nd2 = at32(sc.bvh_nodes, cur << 5);
-        float4 a = nd2[0], b = nd2[1];
-        uint32_t skip = *at32(sc.bvh_skips, (cur << 5) + (oct << 2));   // (its own array: 32-byte boxes keep a sibling pair in one 64-byte stretch — C4 at 16 spp 132.3 → 117.8 ms against links inside a 64-byte node)
+        // TWO loads per node: (centre, B) and the octant's (skip link | split axis << 28, half extent).  The half extent is
+        // repeated in each of a node's eight octant records so that the link and it arrive together: the walks are bound
+        // by the NUMBER of vector memory instructions (one per ~18 cycles per CU on C4).  Links inside a 64-byte node:
+        // C4 at 16 spp 132.3 ms; 32-byte box + a 4-byte link from an array of its own (three loads): 117.8; this: 10 % less again.
+        float4 a = *at32(sc.bvh_nodes, cur << 4);
+        float4 b = *at32(sc.bvh_links, (cur << 7) + (oct << 4));
+        uint32_t skip = __float_as_uint(b.x) & PT_BVH_END;
+        {
+            const uint32_t axis_bits = __float_as_uint(b.x) & 0x30000000u, child = __float_as_uint(a.w);
+            a.w = __uint_as_float(axis_bits);
+            b = make_float4(b.y, b.z, b.w, __uint_as_float(child));
+        }
         uint32_t A = __float_as_uint(a.w), B = __float_as_uint(b.w);
         // (both header words are pinned here: left to itself the compiler fetches the box as two 12-byte loads and
         // the header words only after a hit, one after the other — two more trips to memory on the way down)

@@ -1289,7 +1289,8 @@ struct rt_context {
     DevBuf<uint32_t> mbvh_face_idx, mesh_bvh_root;
     bool have_mesh_bvh = false;
     DevBuf<float4> bvh_nodes, bvh_sph;
-    DevBuf<uint32_t> bvh_idx, bvh_skips;
+    DevBuf<uint32_t> bvh_idx;
+    DevBuf<float4> bvh_links;
     uint32_t bvh_node_count = 0;
     float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0}, bvh_rmax = 0;
     int accel = 1;  // RT_OPT_ACCEL: 0 brute force, 1 BVH for >= ACCEL_MIN_SPHERES spheres, 2 always BVH
@@ -1386,7 +1387,7 @@ DeviceScene device_scene(const rt_context *ctx) {
     s.bvh_nodes = ctx->bvh_nodes.p;
     s.bvh_sph = ctx->bvh_sph.p;
     s.bvh_idx = ctx->bvh_idx.p;
-    s.bvh_skips = ctx->bvh_skips.p;
+    s.bvh_links = ctx->bvh_links.p;
     s.bvh_node_count = use_bvh ? ctx->bvh_node_count : 0;
     for (int k = 0; k < 3; k++) { s.bvh_lo[k] = ctx->bvh_lo[k]; s.bvh_hi[k] = ctx->bvh_hi[k]; }
     s.bvh_rmax = ctx->bvh_rmax;
@@ -1690,7 +1691,7 @@ void rt_destroy(rt_context *ctx) {
     ctx->bvh_nodes.release();
     ctx->bvh_sph.release();
     ctx->bvh_idx.release();
-    ctx->bvh_skips.release();
+    ctx->bvh_links.release();
     for (int i = 0; i < rt_context::EV_RING; i++)
         for (int k = 0; k < 3; k++)
             if (ctx->ev[i][k]) (void)hipEventDestroy(ctx->ev[i][k]);
@@ -1820,7 +1821,7 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (all_bvh && !jobs.empty() && jobs.size() < (1u << 16)) HIP_TRY(ctx, ctx->walk_jobs.upload(jobs.data(), jobs.size()));
     }
     ctx->bvh_node_count = 0;
-    if (d->sphere_count > 0 && d->sphere_count < (1u << 26)) {   // (32-bit byte offsets into the node / leaf arrays: at32)
+    if (d->sphere_count > 0 && d->sphere_count < (1u << 24)) {   // (32-bit byte offsets into the node / link / leaf arrays: at32; a node's links are 128 bytes)
         bool finite = true;
         for (uint32_t i = 0; i < d->sphere_count && finite; i++)
             finite = std::isfinite(d->spheres[i].pos.x) && std::isfinite(d->spheres[i].pos.y) &&
@@ -1831,15 +1832,23 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
             bb.order.resize(d->sphere_count);
             for (uint32_t i = 0; i < d->sphere_count; i++) bb.order[i] = i;
             bb.build(0, d->sphere_count);
-            {   // device layout: 32-byte boxes, the skip links in an array of their own
-                std::vector<float4> boxes(bb.nodes.size() / 2);
-                std::vector<uint32_t> sk(bb.nodes.size() * 2);
+            {   // device layout (hit_spheres_bvh): (centre, B) in 16 bytes; per octant (skip | axis << 28, half extent) in 16 bytes
+                std::vector<float4> boxes(bb.nodes.size() / 4), links(bb.nodes.size() * 2);
                 for (size_t n = 0; n < bb.nodes.size() / 4; n++) {
-                    boxes[2 * n] = bb.nodes[4 * n]; boxes[2 * n + 1] = bb.nodes[4 * n + 1];
-                    memcpy(&sk[8 * n], &bb.nodes[4 * n + 2], 32);
+                    boxes[n] = bb.nodes[4 * n];
+                    boxes[n].w = bb.nodes[4 * n + 1].w;
+                    uint32_t A, s8[8];
+                    memcpy(&A, &bb.nodes[4 * n].w, 4);
+                    memcpy(s8, &bb.nodes[4 * n + 2], 32);
+                    for (int o = 0; o < 8; o++) {
+                        const uint32_t w = s8[o] | (A & 0x30000000u);
+                        float4 &l = links[8 * n + o];
+                        l = make_float4(0.0f, bb.nodes[4 * n + 1].x, bb.nodes[4 * n + 1].y, bb.nodes[4 * n + 1].z);
+                        memcpy(&l.x, &w, 4);
+                    }
                 }
                 HIP_TRY(ctx, ctx->bvh_nodes.upload(boxes.data(), boxes.size()));
-                HIP_TRY(ctx, ctx->bvh_skips.upload(sk.data(), sk.size()));
+                HIP_TRY(ctx, ctx->bvh_links.upload(links.data(), links.size()));
             }
             HIP_TRY(ctx, ctx->bvh_sph.upload(bb.leaf_sph.data(), bb.leaf_sph.size()));
             HIP_TRY(ctx, ctx->bvh_idx.upload(bb.leaf_idx.data(), bb.leaf_idx.size()));
