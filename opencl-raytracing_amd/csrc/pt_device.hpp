@@ -193,13 +193,25 @@ enum {
 
 // What a device function needs besides the scene: the workgroup's LDS copy of
 // the materials and the lane's counters.
+// The staged tables are addressed through LDS-qualified pointers: an `if (table) … else (global record) …` then
+// stays a ds_read and a global load in two branches.  Through generic pointers the compiler merges the two reads into
+// ONE flat load of a selected pointer — a dozen v_cndmask to build the address, and a vector-memory instruction
+// (the queue kernels are bound by their number as much as by ALU work) where an LDS read would do.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(3))) *LdsV4;
+PT_DEV float4 lds_ld(LdsV4 p, uint32_t i) {
+    v4f t = p[i];
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+PT_DEV LdsV4 lds_ptr(const float4 *generic) { return (LdsV4)generic; }
+
 struct Ctx {
     const DeviceScene &sc;
-    const float4 *lmat;  // LDS: [2i] = (r,g,b,extra), [2i+1].x = type bits; nullptr → read global
+    LdsV4 lmat;  // LDS: [2i] = (r,g,b,extra), [2i+1].x = type bits; nullptr → read global
     LaneCounters *cn;
     const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
-    const float4 *lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
-    const float4 *lpln = nullptr;  // LDS (normal, mat) of small plane sets, or nullptr
+    LdsV4 lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
+    LdsV4 lpln = nullptr;  // LDS (normal, mat) of small plane sets, or nullptr
 #if PT_STAMPS
     mutable unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     mutable unsigned long long st_last = 0;
@@ -226,7 +238,7 @@ PT_HD uint32_t lds_static_used(uint32_t material_count, uint32_t sphere_count, u
     return lds_mat_n(material_count) + lds_win_n(sphere_count) + lds_pln_n(plane_count);  // float4 units
 }
 // call at kernel start by every thread of the workgroup (contains a barrier)
-PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
+PT_DEV LdsV4 stage_materials(const DeviceScene &sc, float4 *lds) {
     const uint32_t nm = lds_mat_n(sc.material_count), nw = lds_win_n(sc.sphere_count), np = lds_pln_n(sc.plane_count);
     if (nm)
         for (uint32_t i = threadIdx.x; i < sc.material_count; i += blockDim.x) {
@@ -252,13 +264,13 @@ PT_DEV const float4 *stage_materials(const DeviceScene &sc, float4 *lds) {
             lds[nm + nw + i] = make_float4(p.normal.x, p.normal.y, p.normal.z, __uint_as_float(p.mat_ID));
         }
     __syncthreads();
-    return nm ? lds : nullptr;
+    return nm ? lds_ptr(lds) : (LdsV4) nullptr;
 }
-PT_DEV const float4 *staged_winners(const DeviceScene &sc, const float4 *lds) {
-    return lds_win_n(sc.sphere_count) ? lds + lds_mat_n(sc.material_count) : nullptr;
+PT_DEV LdsV4 staged_winners(const DeviceScene &sc, const float4 *lds) {
+    return lds_win_n(sc.sphere_count) ? lds_ptr(lds + lds_mat_n(sc.material_count)) : (LdsV4) nullptr;
 }
-PT_DEV const float4 *staged_planes(const DeviceScene &sc, const float4 *lds) {
-    return lds_pln_n(sc.plane_count) ? lds + lds_mat_n(sc.material_count) + lds_win_n(sc.sphere_count) : nullptr;
+PT_DEV LdsV4 staged_planes(const DeviceScene &sc, const float4 *lds) {
+    return lds_pln_n(sc.plane_count) ? lds_ptr(lds + lds_mat_n(sc.material_count) + lds_win_n(sc.sphere_count)) : (LdsV4) nullptr;
 }
 // PT_LDS_SPHERES experiment: stage the sphere test data of small scenes (after stage_materials' barrier
 // has been passed by every thread; contains its own barrier)
@@ -272,8 +284,8 @@ PT_DEV const float4 *stage_spheres(const DeviceScene &sc, float4 *lds) {
 
 PT_DEV void load_material(const Ctx &c, uint32_t id, int &type, float &extra, V3 &col) {
     if (c.lmat) {
-        float4 a = c.lmat[2 * id];
-        type = __float_as_int(c.lmat[2 * id + 1].x);
+        float4 a = lds_ld(c.lmat, 2 * id);
+        type = __float_as_int(lds_ld(c.lmat, 2 * id + 1).x);
         extra = a.w;
         col = mk(a.x, a.y, a.z);
     } else {
@@ -654,7 +666,7 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
             if (cand) {
                 uint32_t j = (uint32_t)__builtin_ctz(cand);
                 cand &= cand - 1u;
-                float4 w = c.lwin[2 * j];
+                float4 w = lds_ld(c.lwin, 2 * j);
                 float t = sphere_t(r, make_float4(w.x, w.y, w.z, w.w * w.w));  // r·r: the product the host stored in sph4
                 if (t < best_t) { best_t = t; best_id = K_SPHERE | j; }
             }
@@ -839,7 +851,7 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
     if (kind == K_PLANE) {
         V3 n;
         if (c.lpln) {
-            float4 w = c.lpln[idx];
+            float4 w = lds_ld(c.lpln, idx);
             n = xyz(w);
             hit.mat = __float_as_uint(w.w);
         } else {
@@ -866,10 +878,10 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
         float rad;
         if (SIMPLE || kind == K_SPHERE) {
             if (c.lwin) {
-                float4 w = c.lwin[2 * idx];
+                float4 w = lds_ld(c.lwin, 2 * idx);
                 centre = xyz(w);
                 rad = w.w;
-                hit.mat = __float_as_uint(c.lwin[2 * idx + 1].x);
+                hit.mat = __float_as_uint(lds_ld(c.lwin, 2 * idx + 1).x);
             } else {
                 const rt_sphere &s = sc.spheres[idx];
                 centre = ld3(s.pos);
@@ -953,7 +965,7 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
         // 1/extra and Schlick's r0² per material: from the workgroup's LDS table when there is one
         float inv_extra, r0_extra, r0_inv;
         if (c.lmat) {
-            float4 x = c.lmat[2 * h.mat + 1];
+            float4 x = lds_ld(c.lmat, 2 * h.mat + 1);
             inv_extra = x.y; r0_extra = x.z; r0_inv = x.w;
         } else {
             inv_extra = 1.0f / extra;
