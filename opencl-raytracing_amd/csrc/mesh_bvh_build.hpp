@@ -26,6 +26,39 @@ inline void bvh_centre_half(const float lo[3], const float hi[3], float c[3], fl
     }
 }
 
+// binary16 bit pattern of a non-negative binary32, rounded up (to +inf above 65504; never a subnormal: at least 2^-14)
+// or down (at most 65504; below 2^-14: 0)
+inline uint32_t bvh_half_bits(float x, bool up) {
+    if (!(x > 0.0f)) return up ? 0x0400u : 0u;          // (0, negative, NaN: the smallest normal, resp. 0)
+    if (x >= 65504.0f) return (up && x > 65504.0f) ? 0x7C00u : 0x7BFFu;
+    if (x < 6.103515625e-05f) return up ? 0x0400u : 0u;
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    uint32_t e = (u >> 23) - 127u + 15u, m = u & 0x7FFFFFu;
+    uint32_t h = (e << 10) | (m >> 13);
+    if (up && (m & 0x1FFFu)) h++;                       // (a carry runs into the exponent: the next binade, or inf)
+    return h;
+}
+inline float bvh_half_value(uint32_t h) {
+    uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    if (e == 31u) return INFINITY;
+    if (e == 0u) return std::ldexp((float)m, -24);
+    return std::ldexp((float)(m | 1024u), (int)e - 25);
+}
+// builder's node (4 float4) → device node (3 float4): half extent, sin alpha and longest edge rounded up, q down
+inline void mesh_node_pack(const float4 *nd, float4 *out) {
+    out[0] = nd[0];
+    out[1] = make_float4(nd[2].x, nd[2].y, nd[2].z, nd[1].w);
+    const uint32_t p0 = bvh_half_bits(nd[1].x, true) | bvh_half_bits(nd[1].y, true) << 16;
+    const uint32_t p1 = bvh_half_bits(nd[1].z, true) | bvh_half_bits(nd[3].x, true) << 16;
+    const uint32_t p2 = bvh_half_bits(nd[3].z, true) | bvh_half_bits(nd[3].w, false) << 16;
+    out[2] = nd[3];   // (.y = the smallest face index, kept as it is in .w below)
+    out[2].w = nd[3].y;
+    memcpy(&out[2].x, &p0, 4);
+    memcpy(&out[2].y, &p1, 4);
+    memcpy(&out[2].z, &p2, 4);
+}
+
 struct MeshBvhBuilder {
     // inputs: the mesh's face records (3 float4 per face: A, e1, e2, n as DeviceScene::faces)
     const float4 *rec = nullptr;

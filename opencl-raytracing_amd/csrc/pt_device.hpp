@@ -165,7 +165,7 @@ struct DeviceScene {
     const float4 *faces;
     const uint32_t *mesh_face_base;
     // optional per-mesh BVHs (pt_mesh_bvh.hpp); mesh_bvh_root == nullptr or root == NONE → face scan
-    const float4 *mbvh_nodes;       // 4 float4 per node
+    const float4 *mbvh_nodes;       // 3 float4 per node (pt_mesh_bvh.hpp)
     const float4 *mbvh_faces;       // face records (as `faces`) in leaf order
     const uint32_t *mbvh_face_idx;  // their face index inside the mesh
     const uint32_t *mesh_bvh_root;  // per mesh

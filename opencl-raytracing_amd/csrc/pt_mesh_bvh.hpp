@@ -36,8 +36,10 @@
 // tests/test_gpu_properties.py::test_mesh_bvh_keeps_faces_accepted_far_from_the_ray drives rays the
 // reference accepts 2–5 edge lengths away from the face through this walk.
 //
-// Node = 4 float4: (box centre.xyz, A) (box half extent.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
+// Builder's node = 4 float4: (box centre.xyz, A) (box half extent.xyz, B) (cone axis.xyz, cos alpha) (sin alpha, min face, longest edge, q)
 //   A = skip link (the node after this subtree; PT_MESH_END = none);  B = left child, or leaf: 0x80000000 | count << 28 | first face slot
+// Device node = 3 float4 (mesh_node_pack in mesh_bvh_build.hpp): (centre.xyz, A) (cone axis.xyz, B)
+//   (half extent.x | .y << 16, half extent.z | sin alpha << 16, longest edge | q << 16, min face) — the pairs are binary16.
 // (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
 #pragma once
 
@@ -84,6 +86,8 @@ struct WalkStat { unsigned long long steps, node_lanes, leaf_runs, leaf_lanes, i
 
 #define PT_MESH_END 0x0FFFFFFFu
 #define PT_MESH_PARKED 0x80000000u
+PT_DEV float half_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu)); }
+PT_DEV float half_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
 struct MeshWalk {
     uint32_t cur;   // the node to be tested next | PT_MESH_PARKED: met leaf whose faces are still to be tested;  PT_MESH_END: through
 };
@@ -187,12 +191,19 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uin
         }
 #endif
         if (cur < PT_MESH_END) {
-            const float4 *nd = at32(sc.mbvh_nodes, cur << 6);
-            float4 a = nd[0], b = nd[1], cn = nd[2], ex = nd[3];
-            // (pinned: left to itself the compiler fetches cn as 12 bytes and cn.w only after the index test has
-            // passed — a second trip to memory in every node test)
-            asm("" : "+v"(cn.w), "+v"(a.w), "+v"(b.w));
-            const uint32_t B = __float_as_uint(b.w);
+            // THREE 16-byte loads per node (the walk is bound by the number of vector memory instructions as much as by
+            // its ALU work): the box's half extent, sin alpha, the longest edge and q travel as binary16, rounded to the
+            // safe side by the host (mesh_node_pack); cos alpha is derived from sin alpha.
+            const float4 *nd = at32(sc.mbvh_nodes, cur * 48u);
+            float4 a = nd[0], cn = nd[1], pk = nd[2];
+            // (pinned: left to itself the compiler splits the loads and fetches some words only after a branch)
+            asm("" : "+v"(a.w), "+v"(cn.w), "+v"(pk.x), "+v"(pk.w));
+            const uint32_t B = __float_as_uint(cn.w);
+            const uint32_t p0 = __float_as_uint(pk.x), p1 = __float_as_uint(pk.y), p2 = __float_as_uint(pk.z);
+            const float sin_a = half_hi(p1);
+            float4 b = make_float4(half_lo(p0), half_hi(p0), half_lo(p1), cn.w);
+            float4 ex = make_float4(sin_a, pk.w, half_lo(p2), half_hi(p2));
+            cn.w = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-sin_a, sin_a, 1.0f)));
             if (mesh_node_miss<MODE>(r, k, a, b, cn, ex, best_face, dbg)) cur = __float_as_uint(a.w) & PT_MESH_END;
             else if (B & 0x80000000u) cur |= PT_MESH_PARKED;
             else cur = B;
@@ -206,7 +217,7 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uin
             if (ws) { ws->leaf_runs++; ws->leaf_lanes += __popcll(__ballot(parked)); }
 #endif
             if (parked) {
-                const float4 *nd = at32(sc.mbvh_nodes, (cur & PT_MESH_END) << 6);
+                const float4 *nd = at32(sc.mbvh_nodes, (cur & PT_MESH_END) * 48u);
                 uint32_t A = __float_as_uint(nd[0].w), B = __float_as_uint(nd[1].w);
                 uint32_t first = B & 0x0FFFFFFFu, cnt = (B >> 28) & 7u;
                 for (uint32_t j = 0; j < cnt; j++) {

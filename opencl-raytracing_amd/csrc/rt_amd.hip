@@ -1806,7 +1806,11 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (nodes.size() / 4 >= (1u << 26) || lidx.size() >= (1u << 26)) ctx->have_mesh_bvh = false;
         if (nodes.empty()) nodes.resize(4, make_float4(0, 0, 0, 0));
         if (lfaces.empty()) lfaces.resize(3, make_float4(0, 0, 0, 0));
-        HIP_TRY(ctx, ctx->mbvh_nodes.upload(nodes.data(), nodes.size()));
+        {   // device layout: 48 bytes per node (mesh_node_pack)
+            std::vector<float4> packed(nodes.size() / 4 * 3);
+            for (size_t n = 0; n < nodes.size() / 4; n++) mesh_node_pack(&nodes[4 * n], &packed[3 * n]);
+            HIP_TRY(ctx, ctx->mbvh_nodes.upload(packed.data(), packed.size()));
+        }
         HIP_TRY(ctx, ctx->mbvh_faces.upload(lfaces.data(), lfaces.size()));
         HIP_TRY(ctx, ctx->mbvh_face_idx.upload(lidx.data(), lidx.size()));
         HIP_TRY(ctx, ctx->mesh_bvh_root.upload(roots.data(), d->mesh_count));
@@ -2337,6 +2341,20 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
         std::vector<uint32_t> all;
         e = collect(root, all);
         if (!e.empty()) return bad("mesh bvh: " + e);
+        // the device's 48-byte form of every node (mesh_node_pack): binary16 fields rounded to the safe side
+        for (size_t n = root; n < nodes.size() / 4; n++) {
+            const float4 *nd = &nodes[4 * n];
+            float4 pk[3];
+            mesh_node_pack(nd, pk);
+            uint32_t p[3];
+            memcpy(p, &pk[2], 12);
+            const float hx = bvh_half_value(p[0] & 0xFFFFu), hy = bvh_half_value(p[0] >> 16), hz = bvh_half_value(p[1] & 0xFFFFu);
+            const float sn = bvh_half_value(p[1] >> 16), em = bvh_half_value(p[2] & 0xFFFFu), q = bvh_half_value(p[2] >> 16);
+            if (!(hx >= nd[1].x && hy >= nd[1].y && hz >= nd[1].z)) return bad("mesh bvh: packed half extent below the node's");
+            if (!(sn >= nd[3].x) || !(em >= nd[3].z) || !(q <= nd[3].w)) return bad("mesh bvh: packed cone / edge / quality on the wrong side");
+            if (memcmp(&pk[0], &nd[0], 16) || memcmp(&pk[1], &nd[2], 12) || memcmp(&pk[1].w, &nd[1].w, 4) || memcmp(&pk[2].w, &nd[3].y, 4))
+                return bad("mesh bvh: packed node differs in an unpacked field");
+        }
         stats[3] += st.nodes; stats[4] += st.leaves; stats[5] = std::max(stats[5], st.max_depth); stats[6]++;
     }
     return RT_OK;
