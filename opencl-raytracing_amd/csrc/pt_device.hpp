@@ -454,6 +454,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     // place, the leaf block (up to four sphere tests with their square roots) ran on almost every step for one or
     // two lanes.
     uint32_t cur = 1u;   // (the root; node 0 is padding so that sibling pairs start at even indices)
+    uint32_t best_slot = PT_NO_HIT;   // this walk's nearest sphere so far (the spheres come first in the search: best_id is PT_NO_HIT on entry)
     bool at_leaf = false;
     uint32_t leaf_b = 0, leaf_skip = 0;
     for (uint32_t guard = 0; guard < sc.bvh_node_count + 8u; guard++) {  // every node is tested at most once
@@ -508,13 +509,16 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
                 uint32_t first = leaf_b & 0x0FFFFFFFu, cnt = (leaf_b >> 28) & 7u;
                 for (uint32_t k = 0; k < cnt; k++) {
                     if (COUNT) cn->c[CN_DBG_BVH_TESTS]++;
-                    float4 sp = *at32(sc.bvh_sph, (first + k) << 4);
-                    uint32_t idx = *at32(sc.bvh_idx, (first + k) << 2);
-                    asm("" : "+v"(idx), "+v"(sp.x));   // (fetched together; the index is needed after a hit only)
-                    float t = sphere_t(r, sp);
-                    if (t < best_t || (t == best_t && best_id != PT_NO_HIT && idx < (best_id & ~K_MASK))) {
+                    // ONE load per sphere: the winner is kept as a leaf slot and translated to the sphere's own index
+                    // once, after the walk; two spheres at exactly the same t (the smaller index wins, as in the
+                    // reference's in-order scan with strict '<') fetch their indices on the spot
+                    float t = sphere_t(r, *at32(sc.bvh_sph, (first + k) << 4));
+                    bool take = t < best_t;
+                    if (t == best_t && best_slot != PT_NO_HIT)
+                        take = *at32(sc.bvh_idx, (first + k) << 2) < *at32(sc.bvh_idx, best_slot << 2);
+                    if (take) {
                         best_t = t;
-                        best_id = K_SPHERE | idx;
+                        best_slot = first + k;
                     }
                 }
                 at_leaf = false;
@@ -523,6 +527,7 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
         }
         if (__all(cur == PT_BVH_END)) break;
     }
+    if (best_slot != PT_NO_HIT) best_id = K_SPHERE | *at32(sc.bvh_idx, best_slot << 2);
 }
 
 #ifndef PT_PACKED_SPHERES
