@@ -315,7 +315,9 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
                                            paths end; 0: one fixed sample set per lane                  */
 #define RT_OPT_ACCEL 4                  /* sphere / mesh search: 0 brute force (the reference's loops), 1
                                            (default) conservative BVHs for >= 64 spheres and for meshes of
-                                           >= 32 faces, 2 sphere BVH always.  Same winner in every mode   */
+                                           >= 32 faces, 2 sphere BVH always.  Same winner in every mode
+                                           (a set of >= 2^24 spheres, or meshes of >= 2^26 BVH nodes in all,
+                                           take the brute-force loops: the walks address 32-bit offsets)      */
 #define RT_OPT_WALK_SLICES 5            /* 1 (default): in scenes where every mesh of every model has a BVH, the
                                            lanes' mesh walks advance in interleaved slices; 0: every walk runs in place */
 int rt_set_option(rt_context *ctx, int option, int value);
