@@ -57,3 +57,18 @@ def test_degenerate_and_tiny_meshes(built):
     empty = rt.SceneCreator()
     empty.addMaterial(rt._abi.T_DIFFUSE, (1, 1, 1), 1)
     assert rt.check_accel(empty)["sphere_nodes"] == 0
+
+
+@pytest.mark.parametrize("scale", [1e-6, 3e-3, 1.0, 4e4, 1e9])
+def test_packed_mesh_nodes_at_extreme_scales(built, scale):
+    """The device's 48-byte mesh node carries half extent, sin alpha, longest edge and q as binary16
+    (mesh_node_pack): rt_debug_check_accel unpacks every node and checks that each field is rounded
+    to the safe side — here for meshes whose extents fall below binary16's normal range (1e-6: the
+    smallest normal stands in) and above its largest value (4e4, 1e9: +inf, an unbounded box)."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.3)
+    pos, uv, idx = rt.workloads.uv_sphere(40, 24, radius=2.0 * scale, centre=(3.0 * scale, -1.0 * scale, 2.0 * scale))
+    s.addMesh(pos, uv, idx)
+    s.addModel(1, 0)
+    st = rt.check_accel(s)
+    assert st["meshes"] == 1 and st["mesh_leaves"] >= 40 * 23

@@ -590,3 +590,32 @@ def test_walk_slices_with_several_meshes(inside, oracle):
     dev = np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)
     assert dev.max() <= 1e-4, dev.max()
     t.close()
+
+
+@pytest.mark.parametrize("scale", [0.004, 100.0])
+def test_mesh_bvh_small_and_large_worlds(scale):
+    """The packed mesh node (binary16 half extent / cone / edge fields, rounded to the safe side) in a world whose
+    leaf boxes are around binary16's smallest normal (scale 0.004: faces of 1e-5) and in one near the far end of the
+    reference's range of t (scale 100: paths of 300–900 units, MAX_DISTANCE is 1000): BVH walk == face scan, bit for bit, and the frame is not empty."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.3)   # 0
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.8, 0.7, 0.6), 1)  # 1
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)          # 2
+    k = np.float32(scale)
+    pos, uv, idx = rt.workloads.uv_sphere(120, 80, radius=float(0.9 * k), centre=(0.0, float(0.4 * k), 0.0))
+    s.addMesh(pos, uv, idx)
+    s.addModel(1, 0)
+    s.addSphere((float(0.5 * k), float(-8 * k), 0.0), float(5 * k), 2)
+    s.addPlane((0.0, float(1.4 * k), 0.0), (0, 1, 0), 1)
+    cam = rt.Camera(60, 16 / 9, (float(-1.9 * k), float(0.1 * k), float(-1.9 * k)), 45.0, 5.0).transferData()
+    w, h = 160, 90
+    t = rt.RayTracer(w, h, scene=s, seed=cases.SEED)
+    frames = []
+    for accel in (0, 1):
+        t.setOption(t.OPT_ACCEL, accel)
+        t.clear()
+        t.renderSamples(cam, 0, 16)
+        frames.append(t.readLinear())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert (frames[1][..., :3].sum(-1) > 0).mean() > 0.2
+    t.close()
