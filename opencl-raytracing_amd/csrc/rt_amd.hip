@@ -316,10 +316,17 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 // Pixels per wave: as many as the LDS of a CU allows with PT_Q_WAVES(_ACCEL) workgroups resident (6: 160 KB / 6 per
 // workgroup); when that leaves a wave fewer than 384 samples (256 spp and up: the queue's tail grows) the
 // budget of 5 resident workgroups is used instead — the kernel's 80 VGPRs fit either way.
+#ifndef PT_LDS_GRANULE
+#define PT_LDS_GRANULE 1024u
+#endif
 __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, uint32_t static_float4, uint32_t block_waves = 4u) {
     auto fit = [&](uint32_t waves_per_simd) {
         uint32_t workgroups = waves_per_simd * 4u / block_waves;  // resident workgroups per CU
-        uint32_t per_wave = (163840u / workgroups - static_float4 * (uint32_t)sizeof(float4)) / block_waves - 15u;
+        // (LDS is handed out in blocks: a request of 6 584 bytes — 7 pixels of 64 samples — left fewer than 24 workgroups
+        // resident although 24 × 6 584 < 160 KiB, and 6 pixels (5 728 bytes) are 4.5 % faster on C2; the budget is
+        // therefore rounded DOWN to a multiple of PT_LDS_GRANULE)
+        uint32_t budget = 163840u / workgroups / PT_LDS_GRANULE * PT_LDS_GRANULE;
+        uint32_t per_wave = (budget - static_float4 * (uint32_t)sizeof(float4)) / block_waves - 15u;
         uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
