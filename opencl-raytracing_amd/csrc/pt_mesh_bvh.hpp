@@ -23,9 +23,15 @@
 //          smallest |cos(theta)| over the subtree's NORMAL CONE; K = 5e-6 = 3.3 × 25.6 u.  Only when
 //          cosmin > TAU and q > 1e-3 (then |δa| << |a| and the sign of a is right).
 //  cap     the reference rejects |a_computed| < 1e-7 (TRIANGLE_EPSILON), so for emax²·|d| <= 0.04
-//          (|δa| <= 0.2e-7) every accepted face has |a| >= 0.8e-7 whatever the angle, the negative
-//          barycentrics sum to at most N = 19.0·|d|·reach·emax, and the line passes within N·emax of
-//          the face.  m_cap = PT_MESH_CAP·|d|·reach·emax², PT_MESH_CAP = 40 (2.1 × 19.0).
+//          (|δa| <= 8.25u·0.04 = 0.197e-7) every accepted face has |a| >= a_min = 0.8033e-7 whatever the angle.
+//          With X = |d|·reach·emax and u/a_min = 0.742:  -l_B <= 8.25u|s||d||e2|/a_min <= 6.12 X,
+//          -l_C <= 6.43 X,  -l_A <= (6.12 + 6.43) X + 8.25u|d|emax²/a_min + 5u <= 15.61 X + 5u  (emax <= reach/2).
+//          The barycentrics sum to 1, so at most two are negative and their negative parts sum to
+//          S <= (15.61 + 6.43) X = 22.04 X (+ 5u, covered by the additive slack of the slab test); writing the
+//          point as a combination of the vertices, it lies within S·(longest edge) of the face.
+//          m_cap = PT_MESH_CAP·|d|·reach·emax², PT_MESH_CAP = 24 (22.04 + 9 %; dlen, reach and emax are themselves
+//          rounded up by 1e-6, 1e-3 and 1e-4 + the binary16 rounding).  Round 1 carried 40 here — a safety factor
+//          of 1.8 that cost C5 a third of its time (cap 40 / 30 / 20: 39.1 / 31.2 / 25.3 ms at 1080p × 64 spp).
 //  slab    same N, but along a direction x perpendicular to d the line leaves the face's own extent
 //          along x by at most N·(that extent): grazing faces are thin along the part of the cone axis
 //          perpendicular to d, which removes the "silhouette band" (see the code).
@@ -47,7 +53,7 @@
 #define PT_MESH_TAU 2.0e-3f
 #define PT_MESH_K 5.0e-6f
 #ifndef PT_MESH_CAP
-#define PT_MESH_CAP 40.0f
+#define PT_MESH_CAP 24.0f
 #endif
 #ifndef PT_MESH_BACKFACE_CULL
 #define PT_MESH_BACKFACE_CULL 1
