@@ -457,7 +457,10 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
     uint32_t best_slot = PT_NO_HIT;   // this walk's nearest sphere so far (the spheres come first in the search: best_id is PT_NO_HIT on entry)
     bool at_leaf = false;
     uint32_t leaf_b = 0, leaf_skip = 0;
-    for (uint32_t guard = 0; guard < sc.bvh_node_count + 8u; guard++) {  // every node is tested at most once
+    // (the bound counts ITERATIONS: a lane tests every node at most once, and every leaf it meets costs it up to
+    // PT_SPHERE_LEAF_EVERY more — parked until the next leaf phase.  A ray whose direction is far from unit length
+    // (|d|² up to 1.25: the margin then inflates every box by about the distance to it) visits the whole tree.)
+    for (uint32_t guard = 0; guard < (PT_SPHERE_LEAF_EVERY + 1u) * sc.bvh_node_count + 8u; guard++) {
       if (cur != PT_BVH_END && !at_leaf) {
         // TWO loads per node: (centre, B) and the octant's (skip link | split axis << 28, half extent).  The half extent is
         // repeated in each of a node's eight octant records so that the link and it arrive together: the walks are bound
