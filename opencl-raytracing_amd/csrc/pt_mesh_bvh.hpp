@@ -15,7 +15,7 @@
 // A face the reference accepts therefore has exact barycentrics (of the point where the
 // ray's LINE meets the face's plane; equivalently of the line seen along d) with
 //     l_B >= −|δnu|/|a|,  l_C >= −|δnv|/|a|,  l_A >= −(|δnu| + |δnv| + |δa|)/|a| − 4u.
-// Three margins follow, all used below with |s| <= reach = dfar + 2·emax (dfar = largest
+// Three margins follow, all used below with |s| <= dfar <= reach = dfar + 2·emax (dfar = largest
 // distance origin → node box, emax = longest edge of the subtree):
 //  steep   |a| = |d| |e1| |e2| sin(phi) |cos(theta)|: the accepted region is the face grown by at most
 //          u·G·|s| / (sin(phi)·|cos(theta)|), G a shape factor (25.6 equilateral; mesh_bvh_build.hpp).
@@ -24,14 +24,17 @@
 //          cosmin > TAU and q > 1e-3 (then |δa| << |a| and the sign of a is right).
 //  cap     the reference rejects |a_computed| < 1e-7 (TRIANGLE_EPSILON), so for emax²·|d| <= 0.04
 //          (|δa| <= 8.25u·0.04 = 0.197e-7) every accepted face has |a| >= a_min = 0.8033e-7 whatever the angle.
-//          With X = |d|·reach·emax and u/a_min = 0.742:  -l_B <= 8.25u|s||d||e2|/a_min <= 6.12 X,
-//          -l_C <= 6.43 X,  -l_A <= (6.12 + 6.43) X + 8.25u|d|emax²/a_min + 5u <= 15.61 X + 5u  (emax <= reach/2).
+//          Every vertex lies in the node's box, so |s| <= dfar; with u/a_min = 0.742:
+//              -l_B <= 8.25u|s||d||e2|/a_min <= 6.12·|d|·dfar·emax,      -l_C <= 6.43·|d|·dfar·emax,
+//              -l_A <= (6.12 + 6.43)·|d|·dfar·emax + 8.25u|d|emax²/a_min + 5u = 12.55·|d|·dfar·emax + 6.12·|d|·emax² + 5u.
 //          The barycentrics sum to 1, so at most two are negative and their negative parts sum to
-//          S <= (15.61 + 6.43) X = 22.04 X (+ 5u, covered by the additive slack of the slab test); writing the
+//          S <= |d|·emax·(18.98·dfar + 6.12·emax) (+ 5u, covered by the additive slack of the slab test); writing the
 //          point as a combination of the vertices, it lies within S·(longest edge) of the face.
-//          m_cap = PT_MESH_CAP·|d|·reach·emax², PT_MESH_CAP = 24 (22.04 + 9 %; dlen, reach and emax are themselves
-//          rounded up by 1e-6, 1e-3 and 1e-4 + the binary16 rounding).  Round 1 carried 40 here — a safety factor
-//          of 1.8 that cost C5 a third of its time (cap 40 / 30 / 20: 39.1 / 31.2 / 25.3 ms at 1080p × 64 spp).
+//          m_cap = |d|·emax²·(PT_MESH_CAP_D·dfar + PT_MESH_CAP_E·emax) with the two bounds + 9 % (20.7, 6.7); dlen, dfar
+//          and emax are themselves rounded up (1e-6, 1e-3, 1e-4 + the binary16 rounding).  Round 1 carried
+//          40·|d|·(dfar + 2·emax)·emax² here — a safety factor of 1.8 (and three times that for the nodes next to a
+//          ray's origin) that cost C5 more than a third of its time: 39.1 ms → 27.2 (24·(dfar + 2·emax)) → 24.9 (this form)
+//          at 1080p × 64 spp.
 //  slab    same N, but along a direction x perpendicular to d the line leaves the face's own extent
 //          along x by at most N·(that extent): grazing faces are thin along the part of the cone axis
 //          perpendicular to d, which removes the "silhouette band" (see the code).
@@ -52,8 +55,11 @@
 #define PT_MESH_BVH_NONE 0xFFFFFFFFu
 #define PT_MESH_TAU 2.0e-3f
 #define PT_MESH_K 5.0e-6f
-#ifndef PT_MESH_CAP
-#define PT_MESH_CAP 24.0f
+#ifndef PT_MESH_CAP_D
+#define PT_MESH_CAP_D 20.7f
+#endif
+#ifndef PT_MESH_CAP_E
+#define PT_MESH_CAP_E 6.7f
 #endif
 #ifndef PT_MESH_BACKFACE_CULL
 #define PT_MESH_BACKFACE_CULL 1
@@ -150,7 +156,7 @@ PT_DEV bool mesh_node_miss(const Ray &r, const MeshCull &k, float4 a, float4 b, 
             float reach = __builtin_fmaf(2.0f, ex.z, dfar);
             // (a margin: the reciprocal is the hardware's, scaled up by 2^-19 — K itself carries a factor 3.3 of slack)
             float m_steep = steep ? PT_MESH_K * reach * (__builtin_amdgcn_rcpf(ex.w * cosmin) * 1.000002f) : INFINITY;
-            float m_cap = capped ? PT_MESH_CAP * dlen * reach * ex.z * ex.z : INFINITY;
+            float m_cap = capped ? dlen * ex.z * ex.z * __builtin_fmaf(PT_MESH_CAP_D, dfar, PT_MESH_CAP_E * ex.z) : INFINITY;
             float m = fminf(m_steep, m_cap) + __builtin_fmaf(1.0e-5f, dfar + o_max, 1.0e-6f);
             // per axis the line is inside the inflated slab for t in [tc − te, tc + te], tc = (c − o)/d, te = (h + m)/|d|
             // (the rounding of this form, 2^-24·(3·dfar + o_max) in units of distance, is 50 × below the slack in m)

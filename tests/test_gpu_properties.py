@@ -452,7 +452,8 @@ def test_mesh_bvh_keeps_faces_accepted_far_from_the_ray(edge, oracle):
     position is several edge lengths away from the ray (the errors grow with the distance of the
     origin).  Such rays are found here with the oracle's hitTriangle, made the (only) primary ray of a
     tiny frame, and the mesh BVH must still agree bit for bit with the face scan.  (A build with
-    -DPT_MESH_CAP=0.2f, the cap margin at 0.003 of its value, fails this test.)"""
+    -DPT_MESH_CAP=0.2f — the cap margin at 0.5 % of its round-1 value; today -DPT_MESH_CAP_D=0.1f -DPT_MESH_CAP_E=0.03f —
+    fails this test.)"""
     s, pos, tri = _displaced_acceptance_scene(edge)
     rng = np.random.RandomState(11)
     n = 600000
