@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* error codes */
 #define RT_OK 0
@@ -320,6 +320,22 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
                                            take the brute-force loops: the walks address 32-bit offsets)      */
 #define RT_OPT_WALK_SLICES 5            /* 1 (default): in scenes where every mesh of every model has a BVH, the
                                            lanes' mesh walks advance in interleaved slices; 0: every walk runs in place */
+#define RT_OPT_ARITH 6                  /* the ARITHMETIC POLICY of the trace kernels (csrc/pt_arith.hpp).  The reference's
+                                           random numbers are table entries indexed by a hash of the ray direction
+                                           (raytracer.cl:113-125): one ulp re-routes a path, so "the reference's
+                                           result" exists only relative to one definition of the OpenCL builtins, of
+                                           `/`, sqrt and of the contraction of a*b+c.  Unlike the other options this
+                                           one CHANGES THE RESULT — it selects which build of the reference is matched
+                                           bit for bit per pixel-sample:                                          */
+#define RT_ARITH_IEEE 0                 /*   (default) plain IEEE-754 builtins, correctly rounded / and sqrt, no fused
+                                             multiply-add: the reference compiled -ffp-contract=off for a CPU with the
+                                             builtin formulas of oracle/ref_shim.cpp — what the CPU oracle restates   */
+#define RT_ARITH_ROCM_OCL_NOCONTRACT 1  /*   the reference built by ROCm's OpenCL tool chain for gfx950 with
+                                             -ffp-contract=off: ROCm's builtin library (fma-chain dot / cross / mix,
+                                             v_rsq_f32 normalize, ocml pow), 2.5-ulp `/`, 3-ulp sqrt               */
+#define RT_ARITH_ROCM_OCL 2             /*   the same with OpenCL's DEFAULT flags: clang also contracts the kernel's
+                                             own a*b+c expressions — what an unmodified KernelGL::buildProgram
+                                             (src/kernelgl.cpp:95-106, no build options) gets from ROCm's OpenCL    */
 int rt_set_option(rt_context *ctx, int option, int value);
 
 /* ---- measurement --------------------------------------------------------- */
@@ -341,6 +357,12 @@ int rt_debug_check_accel(const rt_scene_desc *scene, uint64_t stats[8], char *er
 /* Diagnostics of the sphere search since the last reset (counting build only):
  * out[0] = BVH nodes entered, out[1] = sphere tests actually executed. */
 int rt_get_debug_counters(rt_context *ctx, uint64_t out[2]);
+
+/* Sticky flags "a BVH walk left its loop on its iteration bound instead of at the end of the tree" since the last
+ * rt_reset_counters(): bit 0 sphere walk, bit 1 mesh walk, bit 2 the walk-slice kernel's outer loop.  Such a walk
+ * may return a wrong nearest hit; the bounds are sized so that it cannot happen, and every GPU test and bench.py's
+ * parity leg assert 0 here. */
+int rt_walk_overflow(rt_context *ctx, uint32_t *flags_out);
 
 /* Algorithmic bytes of the reference kernel for these counters
  * (SURVEY §8d): 32·t_sphere + 48·t_plane + 64·t_lens + 12·t_model +
@@ -371,6 +393,11 @@ int rt_debug_hit(rt_context *ctx, int kind, const float *rays, const uint32_t *p
                  float *out12);
 int rt_debug_material(rt_context *ctx, int routine, const float *in16, size_t n, float *out9);
 int rt_debug_div3(rt_context *ctx, const float *in4, size_t n, float *out6);
+/* rt_debug_builtin: ONE builtin of the selected arithmetic policy per record — op 0 dot, 1 cross, 2 normalize,
+ * 3 {a0/a1, 1/a0, (a.yz)/a6}, 4 sqrt, 5 mix(a, b, a6), 6 min, 7 sign, 8 pow(a0, 5), 9 the table hash of a.xyz (uint
+ * bits).  in8: n × 8 floats {a.xyz, b.xyz, t, -}; out4: n × 4 floats.  tests/test_gpu_ref950.py compares policies
+ * 1 / 2 with probe kernels that call ROCm's OpenCL builtins themselves. */
+int rt_debug_builtin(rt_context *ctx, int op, const float *in8, size_t n, float *out4);
 
 /* The two stages of the same calls separately: a fused rt_render_spp call is pt_prefix
  * (first_ms: one work-item per pixel, the sample-invariant path prefix) followed by the

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 DEPTH = 30
 RANDOM_BUFFER_SIZE = 100000
 RANDOM_TABLE_FLOATS = 4 * RANDOM_BUFFER_SIZE

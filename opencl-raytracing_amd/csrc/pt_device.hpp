@@ -2,10 +2,12 @@
 //
 // Hand-written HIP equivalent of everything kernels `trace` / `retrace` of the
 // reference reach (kernels/raytracer.cl:93-494; line numbers below are that
-// file's).  Results are bit-identical per pixel-sample to the reference
-// compiled without FMA contraction: every float operation below is a single
-// IEEE-754 binary32 operation in the reference's evaluation order.  This file
-// must be compiled with -ffp-contract=off and without any fast-math flag.
+// file's).  Every float operation below is the reference's operation at that place, in the
+// reference's evaluation order, with the builtins, `/`, sqrt and the contraction of a*b+c as the
+// translation unit's ARITHMETIC POLICY defines them (pt_arith.hpp): policy 0 is bit-identical per
+// pixel-sample to the reference compiled without FMA contraction and with plain IEEE builtins (the CPU
+// oracle's pin), policies 1 and 2 to the reference as ROCm's own OpenCL tool chain builds it for gfx950
+// (oracle/_ref_gfx950/*.hsaco).  Compile with -ffp-contract=off and without any fast-math flag.
 //
 // Mapping to the hardware:
 //   * the 64 lanes of a wave are 64 samples of one pixel (or 64/g pixels × g
@@ -22,88 +24,9 @@
 //     different materials do not serialise a normalize() each;
 //   * table / texture gathers are the only divergent global-memory accesses.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "pt_arith.hpp"
 
-#include "../../include/rt_amd.h"
-
-namespace pt {
-
-struct V3 {
-    float x, y, z;
-};
-
-#define PT_DEV __device__ __forceinline__
-#define PT_HD __host__ __device__ inline
-
-PT_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
-PT_DEV V3 ld3(const rt_float3 &f) { return V3{f.x, f.y, f.z}; }
-PT_DEV V3 xyz(float4 f) { return V3{f.x, f.y, f.z}; }
-PT_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-PT_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-PT_DEV V3 operator*(V3 a, float k) { return V3{a.x * k, a.y * k, a.z * k}; }
-PT_DEV V3 operator/(V3 a, float k) { return V3{a.x / k, a.y / k, a.z / k}; }
-PT_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
-// dot(a,b) = (ax*bx + ay*by) + az*bz — the builtin definition shared with the oracle
-PT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-PT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-// Three IEEE divisions by ONE denominator (normalize :137,:365,:397; the sphere / lens normal :160,:248).
-// hipcc expands a correctly rounded a / d into
-//     ds = div_scale(d, d, a); as = div_scale(a, d, a); r = rcp(ds); e = fma(-ds, r, 1); r = fma(e, r, r);
-//     q = as * r; t = fma(-ds, q, as); q = fma(t, r, q); t = fma(-ds, q, as); q = div_fmas(t, r, q); div_fixup(q, d, a)
-// (11 instructions, 43 issue cycles per SIMD measured — profiles/r02_valu_microbench.md).  div_scale only rescales
-// operands whose quotient or reciprocal would leave the normal range, div_fmas is a plain fma when nothing was
-// scaled, and div_fixup only replaces the result for zero / infinite / NaN operands.  For operands safely inside
-// the normal range (|a| in [2^-90, 2^60] — in particular a != 0 — and |d| in [2^-30, 2^30]: exponent difference
-// in (-126, 96), numerator exponent field > 23, 1/d normal) the expansion is therefore EXACTLY the plain sequence
-// below, and its reciprocal part (rcp and two fma) depends on the denominator only: computed once and shared by
-// the three numerators — the same operations with the same operands, hence the same bits, in 18 instead of 33
-// instructions.  If any active lane of the wave is outside that range the whole wave takes the compiler's
-// divisions (same bits for the in-range lanes, so the choice of path never shows in the result).
-// tests/test_gpu_units.py::test_div3_is_three_ieee_divisions compares the two paths on 2^24 operand sets.
-#ifndef PT_DIV3
-#define PT_DIV3 0  // A/B on MI355X: bit-identical, 31 % fewer v_rcp and 15 % fewer fma issued, kernel time unchanged (C2 2.424 vs 2.418 ms)
-#endif
-PT_DEV bool div3_in_range(V3 a, float d) {
-    uint32_t ax = __float_as_uint(a.x) & 0x7FFFFFFFu, ay = __float_as_uint(a.y) & 0x7FFFFFFFu,
-             az = __float_as_uint(a.z) & 0x7FFFFFFFu, ad = __float_as_uint(d) & 0x7FFFFFFFu;
-    uint32_t lo = min(min(ax, ay), az), hi = max(max(ax, ay), az);
-    // 2^-90 = 0x12800000, 2^60 = 0x5D800000, 2^-30 = 0x30800000, 2^30 = 0x4E800000 (NaN / inf patterns are above all of them)
-    return lo >= 0x12800000u && hi <= 0x5D800000u && ad >= 0x30800000u && ad <= 0x4E800000u;
-}
-PT_DEV float div_shared(float a, float nd, float r) {
-    float q = a * r;
-    float t = __builtin_fmaf(nd, q, a);
-    q = __builtin_fmaf(t, r, q);
-    t = __builtin_fmaf(nd, q, a);
-    return __builtin_fmaf(t, r, q);
-}
-PT_DEV V3 div3(V3 a, float d) {
-    if (PT_DIV3 && __all(div3_in_range(a, d))) {
-        float nd = -d;
-        float r = __builtin_amdgcn_rcpf(d);
-        float e = __builtin_fmaf(nd, r, 1.0f);
-        r = __builtin_fmaf(e, r, r);
-        return V3{div_shared(a.x, nd, r), div_shared(a.y, nd, r), div_shared(a.z, nd, r)};
-    }
-    return a / d;
-}
-// normalize(v) = v / sqrt(dot(v,v)); sqrtf and '/' are correctly rounded in HIP
-// (-fhip-fp32-correctly-rounded-divide-sqrt is the default and is passed explicitly)
-PT_DEV V3 normalize(V3 a) { return div3(a, sqrtf(dot(a, a))); }
-PT_DEV V3 vmin(V3 a, V3 b) { return V3{b.x < a.x ? b.x : a.x, b.y < a.y ? b.y : a.y, b.z < a.z ? b.z : a.z}; }
-PT_DEV float sign1(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f)); }
-PT_DEV float pow5(float x) {
-    float x2 = x * x;
-    return (x2 * x2) * x;
-}
-// :127 — false for NaN
-PT_DEV bool in_range(float x) { return (x - RT_MAX_DISTANCE) * (x - RT_MIN_DISTANCE) <= 0.0f; }
-
-struct Ray {
-    V3 o, d;
-};
-PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
+namespace PT_NS {
 
 // tuning switches (A/B-tested on MI355X; results never depend on them)
 #ifndef PT_RNG_PREFETCH
@@ -135,61 +58,6 @@ PT_DEV V3 point_at(const Ray &r, float t) { return r.o + r.d * t; }  // :141
 #define PT_STAMP(c, k) do { } while (0)
 #endif
 
-#define PT_LDS_MATERIALS 64
-#define PT_LDS_WINNERS 64    // spheres whose (pos, r, mat) are also staged in LDS: the winner's record is
-                             // a per-lane fetch on the critical path of every bounce (global: ~600 cycles)  // materials staged in LDS (the .scene grammar allows 10, src/scene.cpp:455)
-#define PT_SPHERE_BATCH 4
-
-// Everything the kernels read.  Passed by value (kernarg segment → SGPRs); this
-// replaces the reference's device-resident Scene struct and its createScene
-// pointer-stashing kernel (:74-91, :541-558).
-struct DeviceScene {
-    const rt_material *materials;
-    const rt_sphere *spheres;
-    const float4 *sph4;  // (cx, cy, cz, r*r) per sphere, padded to whole batches + one dummy batch
-    const rt_plane *planes;
-    const rt_lens *lenses;
-    const rt_float3 *vertices;
-    const rt_float2 *uvs;
-    const uint32_t *indices;
-    const rt_mesh *meshes;
-    const rt_model *models;
-    const float *table;  // 400 000 floats
-    const float4 *tex;   // layers × h × w texels
-    int tex_w, tex_h, tex_layers;
-    float tex_wf, tex_hf;  // (float)tex_w, (float)tex_h: scalar operands of the sampler (converted per lane they end up hoisted into VGPRs)
-    uint32_t material_count, sphere_count, sphere_batches, plane_count, lens_count, model_count;
-    // per-face records of all meshes, 3 float4 each: (A.xyz, e1.x), (e1.yz, e2.xy), (e2.z, n.xyz) with
-    // e1 = B−A, e2 = C−A, n = normalize(cross(e1,e2)) computed once at upload with the same binary32
-    // operations hitTriangle performs per test (:264-265,285); faces of mesh m start at mesh_face_base[m]
-    const float4 *faces;
-    const uint32_t *mesh_face_base;
-    // optional per-mesh BVHs (pt_mesh_bvh.hpp); mesh_bvh_root == nullptr or root == NONE → face scan
-    const float4 *mbvh_nodes;       // 3 float4 per node (pt_mesh_bvh.hpp)
-    const float4 *mbvh_faces;       // face records (as `faces`) in leaf order
-    const uint32_t *mbvh_face_idx;  // their face index inside the mesh
-    const uint32_t *mesh_bvh_root;  // per mesh
-    // optional sphere BVH (see hit_spheres_bvh); bvh_node_count == 0 → brute force
-    const float4 *bvh_nodes;   // 1 float4 per node: (box centre.xyz, left child | leaf)
-    const float4 *bvh_sph;     // spheres in leaf order: (cx, cy, cz, r*r)
-    const uint32_t *bvh_idx;   // their original indices
-    const float4 *bvh_links;   // 8 per node, one per direction octant o: (skip link | split axis << 28, box half extent.xyz) (hit_spheres_bvh)
-    uint32_t bvh_node_count;
-    float bvh_lo[3], bvh_hi[3];  // bounds of all sphere CENTRES
-    float bvh_rmax;              // largest radius
-};
-
-// per-lane work counters (only in COUNT builds)
-#define PT_N_COUNTERS 16
-struct LaneCounters {
-    uint32_t c[PT_N_COUNTERS];
-};
-enum {
-    CN_SAMPLES, CN_BOUNCES, CN_T_SPHERE, CN_T_PLANE, CN_T_LENS, CN_T_MODEL, CN_T_MESH, CN_T_TRI, CN_H_TRI,
-    CN_H_BOUNCE, CN_N_SCATTER, CN_N_DIELECTRIC, CN_N_TEXFETCH, CN_IMAGE_READS,
-    CN_DBG_BVH_NODES,   // diagnostics (rt_get_debug_counters): BVH nodes entered
-    CN_DBG_BVH_TESTS    // sphere tests actually executed (BVH leaves + brute-force fallback)
-};
 
 // What a device function needs besides the scene: the workgroup's LDS copy of
 // the materials and the lane's counters.
@@ -217,8 +85,6 @@ struct Ctx {
     mutable unsigned long long st_last = 0;
 #endif
 };
-#define PT_LDS_PLANES 16     // planes whose (normal, mat) are staged likewise
-#define PT_LDS_STATIC_FLOAT4 (2 * PT_LDS_MATERIALS + 2 * PT_LDS_WINNERS + PT_LDS_PLANES)  // stage_materials' LDS footprint
 
 // :402-403 — r0 = ((1 − ratio)/(1 + ratio))²
 PT_DEV float schlick_r0(float ratio) {
@@ -227,16 +93,6 @@ PT_DEV float schlick_r0(float ratio) {
     return r0;
 }
 
-// ---- materials in LDS ----------------------------------------------------------
-// Compact layout, sized by the scene: materials [0, 2M), sphere winner records [2M, 2M + 2S), plane
-// records after them; a set that exceeds its cap is not staged (0 entries, read from global memory).
-// pt_samples_q sizes its dynamic LDS by lds_static_used(), the other kernels hold the maximum statically.
-PT_HD uint32_t lds_mat_n(uint32_t material_count) { return material_count <= PT_LDS_MATERIALS ? 2u * material_count : 0u; }
-PT_HD uint32_t lds_win_n(uint32_t sphere_count) { return sphere_count <= PT_LDS_WINNERS ? 2u * sphere_count : 0u; }
-PT_HD uint32_t lds_pln_n(uint32_t plane_count) { return plane_count <= PT_LDS_PLANES ? plane_count : 0u; }
-PT_HD uint32_t lds_static_used(uint32_t material_count, uint32_t sphere_count, uint32_t plane_count) {
-    return lds_mat_n(material_count) + lds_win_n(sphere_count) + lds_pln_n(plane_count);  // float4 units
-}
 // call at kernel start by every thread of the workgroup (contains a barrier)
 PT_DEV LdsV4 stage_materials(const DeviceScene &sc, float4 *lds) {
     const uint32_t nm = lds_mat_n(sc.material_count), nw = lds_win_n(sc.sphere_count), np = lds_pln_n(sc.plane_count);
@@ -348,35 +204,42 @@ enum : uint32_t { K_SPHERE = 0u << 30, K_PLANE = 1u << 30, K_LENS = 2u << 30, K_
 // nearest hit then needs ONE comparison, `t < best_t` (best_t <= MAX_DISTANCE), instead of `t > 0 && t < best_t`
 // — a v_cmp costs as much as two multiplies on this chip (profiles/r02_valu_microbench.md).
 #define PT_MISS INFINITY
-// :149-174 with r² precomputed (same float product, computed once at upload).
-// Returns the accepted root, or PT_MISS.
+// :149-174.  s = (centre, r²) with r² the same float product, computed once at upload — or, under policy 2,
+// (centre, r): there `dot(oc,oc) - r*r` and `b*b - c` are contracted (:152-153), so the product never exists on
+// its own.  Returns the accepted root, or PT_MISS.
 PT_DEV float sphere_root(float b, float cc, float dis);
-PT_DEV float sphere_t(const Ray &r, float4 s) {
+PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis) {
     V3 oc = xyz(s) - r.o;
-    float b = dot(oc, r.d);
-    float cc = dot(oc, oc) - s.w;
-    float dis = b * b - cc;
+    b = dot(oc, r.d);
+#if PT_CONTRACT
+    cc = __builtin_fmaf(-s.w, s.w, dot(oc, oc));
+    dis = __builtin_fmaf(b, b, -cc);
+#else
+    cc = dot(oc, oc) - s.w;
+    dis = b * b - cc;
+#endif
+}
+PT_DEV float sphere_t(const Ray &r, float4 s) {
+    float b, cc, dis;
+    sphere_disc(r, s, b, cc, dis);
     return sphere_root(b, cc, dis);
 }
+// what the host stores in the fourth component of a sphere's test record (sph4, bvh_sph)
+#define PT_SPHERE_W_IS_RADIUS PT_CONTRACT
 #define PT_BVH_END 0x0FFFFFFFu
 #ifndef PT_SPHERE_LEAF_EVERY
 #define PT_SPHERE_LEAF_EVERY 4u  // node steps between leaf phases of the sphere BVH walk (power of two)
 #endif
-#ifndef PT_SPHERE_ROUNDS
-#define PT_SPHERE_ROUNDS 0  // A/B: 1 = small scenes record a candidate mask first and take the square roots in per-lane rounds; no gain measured
-#endif
-#ifndef PT_BATCH_ROOTS
-#define PT_BATCH_ROOTS 0  // A/B: 1 = the square-root path of a sphere batch runs once per ROUND (lanes pick their
-#endif                    // first candidate) instead of once per sphere with a handful of lanes active; no gain measured
 // Does this sphere need its roots?  Centre behind the origin (b < 0) and origin outside the sphere
 // (cc > 0): the far root is b + sqrt(b*b - cc) <= |b|·2^-23 < MIN_DISTANCE for |b| < 4096, the near
-// root is negative — the reference rejects both, so the square root is skipped.  Exact.
+// root is negative — the reference rejects both, so the square root is skipped.  Exact.  (Policies 1, 2: the
+// 3-ulp square root makes that |b|·3.6·2^-24; the skip is taken for |b| < 1024 — far root < 2.2e-4.)
 PT_DEV bool sphere_needs_roots(float b, float cc, float dis) {
-    return dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > -4096.0f);
+    return dis > 0 && !(PT_BEHIND_SKIP && b < 0.0f && cc > 0.0f && b > (PT_OCL ? -1024.0f : -4096.0f));
 }
 // :155-171 — the accepted root for dis > 0, or PT_MISS
 PT_DEV float sphere_roots(float b, float dis) {
-    float d = sqrtf(dis);
+    float d = sqrt1(dis);
     float t = PT_MISS;
     float t0 = b - d;
     if (in_range(t0)) t = t0;
@@ -390,13 +253,6 @@ PT_DEV float sphere_roots(float b, float dis) {
 PT_DEV float sphere_root(float b, float cc, float dis) {
     return sphere_needs_roots(b, cc, dis) ? sphere_roots(b, dis) : PT_MISS;
 }
-PT_DEV void sphere_disc(const Ray &r, float4 s, float &b, float &cc, float &dis) {
-    V3 oc = xyz(s) - r.o;
-    b = dot(oc, r.d);
-    cc = dot(oc, oc) - s.w;
-    dis = b * b - cc;
-}
-
 // ---- sphere BVH -------------------------------------------------------------------
 // The reference tests every sphere on every bounce (:327-333).  For large sphere counts
 // the same answer — min over spheres of (t, index), t from the very same sphere_t()
@@ -530,23 +386,10 @@ PT_DEV void hit_spheres_bvh(const DeviceScene &sc, const Ray &r, float &best_t, 
         }
         if (__all(cur == PT_BVH_END)) break;
     }
+    // (cold path: the loop above can only end by its break — a lane still inside the tree here means the iteration
+    // bound was too small and a nearer sphere may have been missed: sticky flag, asserted zero by the tests)
+    if (cur != PT_BVH_END || at_leaf) atomicOr(sc.walk_overflow, PT_OVF_SPHERE_WALK);
     if (best_slot != PT_NO_HIT) best_id = K_SPHERE | *at32(sc.bvh_idx, best_slot << 2);
-}
-
-#ifndef PT_PACKED_SPHERES
-#define PT_PACKED_SPHERES 0  // A/B: two spheres per packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32)
-#endif
-typedef float f2 __attribute__((ext_vector_type(2)));
-// :149-174 for TWO spheres (cx, cy, cz, r²)×2 at once: every step up to the discriminant is one
-// packed-fp32 instruction — two IEEE binary32 results per lane, the same bits as two scalar ops.
-PT_DEV void sphere_pair_t(const Ray &r, float4 sa, float4 sb, float &tA, float &tB) {
-    f2 cx = {sa.x, sb.x}, cy = {sa.y, sb.y}, cz = {sa.z, sb.z}, r2 = {sa.w, sb.w};
-    f2 ocx = cx - r.o.x, ocy = cy - r.o.y, ocz = cz - r.o.z;
-    f2 b = (ocx * r.d.x + ocy * r.d.y) + ocz * r.d.z;
-    f2 cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
-    f2 dis = b * b - cc;
-    tA = sphere_root(b.x, cc.x, dis.x);
-    tB = sphere_root(b.y, cc.y, dis.y);
 }
 
 // :176-194
@@ -561,14 +404,14 @@ PT_DEV float plane_t(const Ray &r, V3 p0, V3 n) {
 PT_DEV float lens_t(const Ray &r, const rt_lens &l, int *which) {
     V3 oc = ld3(l.p1) - r.o;
     float b1 = dot(oc, r.d);
-    float c = dot(oc, oc) - l.r1 * l.r1;
-    float dis1 = b1 * b1 - c;
+    float c = nmad(l.r1, l.r1, dot(oc, oc));   // dot(oc, oc) - r1 * r1   (:199)
+    float dis1 = msub(b1, b1, c);              // b1 * b1 - c            (:200)
     oc = ld3(l.p2) - r.o;
     float b2 = dot(oc, r.d);
-    c = dot(oc, oc) - l.r2 * l.r2;
-    float dis2 = b2 * b2 - c;
+    c = nmad(l.r2, l.r2, dot(oc, oc));
+    float dis2 = msub(b2, b2, c);
     if (dis1 > 0 && dis2 > 0) {
-        float d1 = sqrtf(dis1), d2 = sqrtf(dis2);
+        float d1 = sqrt1(dis1), d2 = sqrt1(dis2);
         float t1A = b1 - d1, t1B = b1 + d1, t2A = b2 - d2, t2B = b2 + d2;
         float t;
         int w;
@@ -645,42 +488,6 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
 #ifndef PT_QSTAT
     if (COUNT && brute) c.cn->c[CN_DBG_BVH_TESTS] += sc.sphere_count;
 #endif
-    if (PT_SPHERE_ROUNDS && brute && sc.sphere_count <= 32u && c.lwin) {
-        // Two passes.  The square-root path of a sphere is needed by the few lanes whose ray meets it, but
-        // a wave runs it whenever ANY lane does — on C2 that is nearly every sphere of every bounce, at
-        // ~5 % lane utilisation.  Pass 1 only records, per lane, WHICH spheres need their roots (the same
-        // discriminant arithmetic, 20 instructions per sphere); pass 2 runs rounds in which every lane
-        // works on its own next candidate (record from LDS), in index order with the reference's strict '<':
-        // as many rounds as the busiest lane has candidates (2-3) instead of one root block per sphere.
-        uint32_t cand = 0;
-        const float4 *sp = sc.sph4;
-        float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
-        for (uint32_t b = 0; b < sc.sphere_batches; b++) {
-            sp += PT_SPHERE_BATCH;
-            float4 n0_ = sp[0], n1_ = sp[1], n2_ = sp[2], n3_ = sp[3];
-            float bb, cc, dd;
-            sphere_disc(r, a0, bb, cc, dd);
-            uint32_t m = sphere_needs_roots(bb, cc, dd) ? 1u : 0u;
-            sphere_disc(r, a1, bb, cc, dd);
-            m |= sphere_needs_roots(bb, cc, dd) ? 2u : 0u;
-            sphere_disc(r, a2, bb, cc, dd);
-            m |= sphere_needs_roots(bb, cc, dd) ? 4u : 0u;
-            sphere_disc(r, a3, bb, cc, dd);
-            m |= sphere_needs_roots(bb, cc, dd) ? 8u : 0u;
-            cand |= m << (b * PT_SPHERE_BATCH);
-            a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
-        }
-        while (__any(cand != 0u)) {
-            if (cand) {
-                uint32_t j = (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                float4 w = lds_ld(c.lwin, 2 * j);
-                float t = sphere_t(r, make_float4(w.x, w.y, w.z, w.w * w.w));  // r·r: the product the host stored in sph4
-                if (t < best_t) { best_t = t; best_id = K_SPHERE | j; }
-            }
-        }
-        brute = false;
-    }
     if (brute && sc.sphere_batches) {
         const float4 *sp = (PT_LDS_SPHERES && c.lsph) ? c.lsph : sc.sph4;
         float4 a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
@@ -688,41 +495,11 @@ PT_DEV void hit_primitives(const Ctx &c, const Ray &r, Nearest &nb) {
             sp += PT_SPHERE_BATCH;  // the array ends with one dummy batch, so this prefetch is always in bounds
             float4 n0_ = sp[0], n1_ = sp[1], n2_ = sp[2], n3_ = sp[3];
             uint32_t i = b * PT_SPHERE_BATCH;
-            if (PT_BATCH_ROOTS) {
-                // discriminants of the four spheres for every lane, then the (long, rarely needed)
-                // root computation in rounds: each lane takes its first pending sphere, so the
-                // sqrt path runs with many lanes active instead of once per sphere with a few.
-                // Per lane the spheres are still visited in index order (strict '<' keeps ties).
-                float b0, c0, d0, b1, c1, d1, b2, c2, d2, b3, c3, d3;
-                sphere_disc(r, a0, b0, c0, d0);
-                sphere_disc(r, a1, b1, c1, d1);
-                sphere_disc(r, a2, b2, c2, d2);
-                sphere_disc(r, a3, b3, c3, d3);
-                bool n0 = sphere_needs_roots(b0, c0, d0), n1 = sphere_needs_roots(b1, c1, d1);
-                bool n2 = sphere_needs_roots(b2, c2, d2), n3 = sphere_needs_roots(b3, c3, d3);
-                while (__any(n0 || n1 || n2 || n3)) {
-                    if (n0 || n1 || n2 || n3) {
-                        uint32_t j = n0 ? 0u : (n1 ? 1u : (n2 ? 2u : 3u));
-                        float bb = n0 ? b0 : (n1 ? b1 : (n2 ? b2 : b3));
-                        float dd = n0 ? d0 : (n1 ? d1 : (n2 ? d2 : d3));
-                        float t = sphere_roots(bb, dd);
-                        if (t < best_t) { best_t = t; best_id = K_SPHERE | (i + j); }
-                        n0 = n0 && j != 0u; n1 = n1 && j != 1u; n2 = n2 && j != 2u; n3 = n3 && j != 3u;
-                    }
-                }
-                a0 = n0_; a1 = n1_; a2 = n2_; a3 = n3_;
-                continue;
-            }
             float t0, t1, t2, t3;
-            if (PT_PACKED_SPHERES) {
-                sphere_pair_t(r, a0, a1, t0, t1);
-                sphere_pair_t(r, a2, a3, t2, t3);
-            } else {
-                t0 = sphere_t(r, a0);
-                t1 = sphere_t(r, a1);
-                t2 = sphere_t(r, a2);
-                t3 = sphere_t(r, a3);
-            }
+            t0 = sphere_t(r, a0);
+            t1 = sphere_t(r, a1);
+            t2 = sphere_t(r, a2);
+            t3 = sphere_t(r, a3);
             if (t0 < best_t) { best_t = t0; best_id = K_SPHERE | i; }
             if (t1 < best_t) { best_t = t1; best_id = K_SPHERE | (i + 1); }
             if (t2 < best_t) { best_t = t2; best_id = K_SPHERE | (i + 2); }
@@ -876,8 +653,8 @@ PT_DEV bool hit_finish(const Ctx &c, const Ray &r, const Nearest &nb, Hit &hit) 
         hit.n = mk(fq.y, fq.z, fq.w);  // normalize(cross(e1, e2)), :285, precomputed per face
         rt_float2 ua = sc.uvs[ia], ub = sc.uvs[ibx], uc = sc.uvs[ic];
         float wgt = 1.0f - best_u - best_v;  // :102
-        hit.u = (ua.x * wgt + ub.x * best_u) + uc.x * best_v;
-        hit.v = (ua.y * wgt + ub.y * best_u) + uc.y * best_v;
+        hit.u = mad(uc.x, best_v, mad(ua.x, wgt, ub.x * best_u));   // (A·w + B·u) + C·v
+        hit.v = mad(uc.y, best_v, mad(ua.y, wgt, ub.y * best_u));
         hit.tex = mesh.texture_ID;
         hit.mat = best_mat;
     } else {
@@ -921,7 +698,7 @@ PT_DEV bool hit_scene(const Ctx &c, const Ray &r, Hit &hit) {
 
 // ---- materials -------------------------------------------------------------------
 // :401-405
-PT_DEV float schlick(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosine); }
+PT_DEV float schlick(float cosine, float r0) { return mad(1.0f - r0, pow5(1.0f - cosine), r0); }   // r0 + (1 - r0) * pow(1 - cai, 5)
 
 // :105-107 with the bilinear definition of DESIGN.md (OpenCL 1.2 §8.2, edge clamp)
 PT_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -965,7 +742,7 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
         out = out * extra;
     } else if (type == RT_REFLECTIVE) {
         float k = 2.0f * dot(r.d, h.n);
-        v = r.d - h.n * k;
+        v = nmad(h.n, k, r.d);   // dir - 2 dot(dir, n) * n
         out = out * extra;  // :366 — only for t_reflective
     } else if (type == RT_REFRACTIVE || type == RT_DIELECTRIC) {
         V3 n;
@@ -997,13 +774,16 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
             float prob = schlick(-cai, r0);
             want = prob < rnd.u;
         }
-        float disc = 1.0f - ratio * ratio * (1.0f - cai * cai);
+        float disc = nmad(ratio * ratio, nmad(cai, cai, 1.0f), 1.0f);   // 1 - ratio * ratio * (1 - cai * cai)   (:381,:424)
         if (want && disc > 0.0f) {
-            v = r.d * ratio - n * (ratio * cai + sqrtf(disc));
+            // ratio * dir - n * (ratio * cai + sqrt(disc))   (:385,:428): the LEFT product is the one clang contracts
+            V3 nk = n * mad(ratio, cai, sqrt1(disc));
+            v = PT_CONTRACT ? mk(__builtin_fmaf(ratio, r.d.x, -nk.x), __builtin_fmaf(ratio, r.d.y, -nk.y), __builtin_fmaf(ratio, r.d.z, -nk.z))
+                            : r.d * ratio - nk;
             renorm = false;
         } else {  // (total internal) reflection about the facing normal
             float k = 2.0f * dot(r.d, n);
-            v = r.d - n * k;
+            v = nmad(n, k, r.d);
         }
     } else {
         return;  // unknown type: the reference's switch has no default (rejected by rt_set_scene)
@@ -1049,24 +829,10 @@ PT_DEV Ray primary_ray(const float *cam, uint32_t x, uint32_t y, int w, int h) {
     Ray r;
     r.o = mk(cam[0], cam[1], cam[2]);
     V3 llc = mk(cam[3], cam[4], cam[5]), hor = mk(cam[6], cam[7], cam[8]), ver = mk(cam[9], cam[10], cam[11]);
-    r.d = normalize((llc + hor * s) + ver * t);
+    r.d = normalize(mad(ver, t, mad(hor, s, llc)));   // llc + s * hor + t * ver
     return r;
 }
 
-// ---- shared deterministic prefix ---------------------------------------------------
-// The reference does not jitter the primary ray (:500-505), so all samples of a
-// pixel follow the SAME path until the first random event (a diffuse / textured /
-// dielectric surface).  That prefix is traced once per pixel (kernel pt_prefix)
-// and stored as a PixelRec; the per-sample kernel continues from it.  Bits are
-// unchanged: the same operations are merely not repeated per sample.
-struct PixelRec {        // 80 bytes
-    float4 p_kind;       // hit point, w = bits: kind (0 final colour, 1 stochastic vertex) | depth << 8 | type << 16
-    float4 n_extra;      // normal, material extra_data
-    float4 d;            // incoming ray direction, w = material id bits
-    float4 out;          // path colour so far (kind 1) or the pixel's radiance for every sample (kind 0)
-    float4 col;          // material colour / texel
-};
-enum { REC_FINAL = 0, REC_VERTEX = 1 };
 
 template <bool COUNT, bool ACCEL>
 PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
@@ -1133,4 +899,4 @@ PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, 
     return trace_from<COUNT, ACCEL>(c, r, out, depth + 1, sample, gx, gy);
 }
 
-}  // namespace pt
+}  // namespace PT_NS

@@ -52,7 +52,6 @@
 // (included inside namespace pt by pt_device.hpp, after triangle_t and DeviceScene)
 #pragma once
 
-#define PT_MESH_BVH_NONE 0xFFFFFFFFu
 #define PT_MESH_TAU 2.0e-3f
 #define PT_MESH_K 5.0e-6f
 #ifndef PT_MESH_CAP_D
@@ -266,6 +265,7 @@ PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root
                               float &fu, float &fv, LaneCounters *dbg = nullptr) {
     MeshWalk w = mesh_walk_start(root);
     uint32_t hits = 0;
-    (void)mesh_bvh_steps<MODE>(sc, r, w, best_face, ft, fu, fv, 0x7FFFFFFFu, hits, dbg);
+    if (!mesh_bvh_steps<MODE>(sc, r, w, best_face, ft, fu, fv, 0x7FFFFFFFu, hits, dbg))
+        atomicOr(sc.walk_overflow, PT_OVF_MESH_WALK);   // cold: the tree has < 2^28 nodes, each tested at most once
     return hits;
 }

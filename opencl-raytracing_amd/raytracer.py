@@ -27,8 +27,13 @@ SYMBOLS = (
     "rt_sync", "rt_trace_samples", "rt_read_image", "rt_read_linear", "rt_device_image", "rt_device_accum",
     "rt_enable_counters", "rt_reset_counters", "rt_get_counters", "rt_counters_bytes", "rt_last_kernel_ms",
     "rt_kernel_ms_history", "rt_stage_ms_history", "rt_debug_hit", "rt_debug_material", "rt_debug_div3", "rt_device_info", "rt_set_option", "rt_shard_slots", "rt_pack_accum", "rt_unpack_accum",
-    "rt_get_debug_counters", "rt_debug_check_accel",
+    "rt_get_debug_counters", "rt_debug_check_accel", "rt_walk_overflow", "rt_debug_builtin",
 )
+
+# rt_set_option: options and the arithmetic policies of RT_OPT_ARITH (include/rt_amd.h)
+OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH = 1, 2, 3, 4, 5, 6
+ARITH_IEEE, ARITH_ROCM_OCL_NOCONTRACT, ARITH_ROCM_OCL = 0, 1, 2
+ARITH_NAMES = {"ieee": ARITH_IEEE, "rocm-opencl-nocontract": ARITH_ROCM_OCL_NOCONTRACT, "rocm-opencl": ARITH_ROCM_OCL}
 
 
 class RtError(RuntimeError):
@@ -102,6 +107,8 @@ def load_library(path=LIB_PATH):
     lib.rt_pack_accum.argtypes = [vp, vp, sz]
     lib.rt_unpack_accum.argtypes = [vp, vp, sz, C.c_int, C.c_int]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.c_char_p, sz]
+    lib.rt_walk_overflow.argtypes = [vp, C.POINTER(u32)]
+    lib.rt_debug_builtin.argtypes = [vp, C.c_int, vp, sz, vp]
     if lib.rt_abi_version() != _abi.RT_ABI_VERSION:
         raise OSError("librt_amd.so ABI %d != expected %d" % (lib.rt_abi_version(), _abi.RT_ABI_VERSION))
     _lib = lib
@@ -333,6 +340,21 @@ class RayTracer:
         self._check(self._lib.rt_get_debug_counters(self._ctx, out))
         return int(out[0]), int(out[1])
 
+    def walkOverflow(self):
+        """Sticky PT_OVF_* bits since resetCounters(): a BVH walk that ended on its loop bound (must be 0)."""
+        out = C.c_uint32()
+        self._check(self._lib.rt_walk_overflow(self._ctx, C.byref(out)))
+        return int(out.value)
+
+    def setArith(self, arith):
+        """Select the arithmetic policy of the trace kernels (RT_OPT_ARITH): ARITH_IEEE (default, the CPU oracle's
+        contract), ARITH_ROCM_OCL_NOCONTRACT or ARITH_ROCM_OCL (the reference as ROCm's OpenCL builds it); a name of
+        ARITH_NAMES is accepted too."""
+        if isinstance(arith, str):
+            arith = ARITH_NAMES[arith]
+        self.setOption(OPT_ARITH, int(arith))
+        self.arith = int(arith)
+
     def lastKernelMs(self):
         ms = C.c_float()
         self._check(self._lib.rt_last_kernel_ms(self._ctx, C.byref(ms)))
@@ -370,6 +392,13 @@ class RayTracer:
         vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1, 16)
         out = np.zeros((len(vec), 9), dtype=np.float32)
         self._check(self._lib.rt_debug_material(self._ctx, routine, vec.ctypes.data, len(vec), out.ctypes.data))
+        return out
+
+    def debugBuiltin(self, op, vec):
+        """One builtin of the selected arithmetic policy per record (rt_debug_builtin): n × 8 floats → n × 4 floats."""
+        vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((len(vec), 4), dtype=np.float32)
+        self._check(self._lib.rt_debug_builtin(self._ctx, op, vec.ctypes.data, len(vec), out.ctypes.data))
         return out
 
     def debugDiv3(self, vec):

@@ -213,7 +213,7 @@ Reference.material = _ref_material
 class ReferenceGfx950(_Base):
     """The reference's kernel file as ROCm's OpenCL tool chain builds it for gfx950 (real builtin
     library: fma-contracted dot, rsq-based normalize, rcp-based divide), executed on the GPU.
-    One process can hold ONE code object (the default build, or the -ffp-contract=off build)."""
+    Several code objects (the default build, the -ffp-contract=off build) can be open in one process."""
 
     @staticmethod
     def available(hsaco=REF950_HSACO):
@@ -222,20 +222,32 @@ class ReferenceGfx950(_Base):
     def __init__(self, hsaco=REF950_HSACO, device=0):
         self.lib = C.CDLL(REF950_SO)
         self.lib.ref950_last_error.restype = C.c_char_p
-        if self.lib.ref950_open(hsaco.encode(), device):
+        self.handle = self.lib.ref950_open(hsaco.encode(), device)
+        if self.handle < 0:
             raise RuntimeError(self.lib.ref950_last_error().decode())
 
-    def render(self, scene, cam, table, w, h, first, count, want_last=False):
+    def render(self, scene, cam, table, w, h, first, count, want_last=False, grid=None):
         """→ (sum over samples first..first+count-1 of the LINEAR radiance, h×w×4 with the count in .w,
-        and optionally the last sample's own frame)."""
+        and optionally the last sample's own frame).  grid = (gw, gh): only the frame's corner x < gw, y < gh is
+        rendered (whole-frame coordinates; everything else stays 0)."""
         if scene.texture_args()[3]:
             raise ValueError("textured scenes need an OpenCL image object; not supported by this tool")
         acc = np.zeros((h, w, 4), dtype=np.float32)
         last = np.zeros((h, w, 4), dtype=np.float32) if want_last else None
         sd = self._scene_args(scene)[0]
         cam, table = _f32(cam), _f32(table)
-        rc = self.lib.ref950_render(sd, _fp(cam), _fp(table), w, h, C.c_uint32(first), C.c_uint32(count), _fp(acc),
-                                    _fp(last) if want_last else None)
+        gw, gh = grid if grid else (0, 0)
+        rc = self.lib.ref950_render(self.handle, sd, _fp(cam), _fp(table), w, h, C.c_uint32(first), C.c_uint32(count),
+                                    int(gw), int(gh), _fp(acc), _fp(last) if want_last else None)
         if rc:
             raise RuntimeError(self.lib.ref950_last_error().decode())
         return (acc, last) if want_last else acc
+
+    def builtin(self, op, vec):
+        """One OpenCL builtin per record, evaluated by ROCm's OpenCL library: n × 8 floats → n × 4 floats."""
+        vec = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((len(vec), 4), dtype=np.float32)
+        rc = self.lib.ref950_builtin(self.handle, int(op), _fp(vec), C.c_size_t(len(vec)), _fp(out))
+        if rc:
+            raise RuntimeError(self.lib.ref950_last_error().decode())
+        return out

@@ -25,8 +25,13 @@
 namespace {
 
 std::string g_err;
-hipModule_t g_mod = nullptr;
-hipFunction_t g_create = nullptr, g_frame = nullptr;
+// one entry per code object (the default build and the -ffp-contract=off build can be open side by side)
+struct Module {
+    std::string path;
+    hipModule_t mod = nullptr;
+    hipFunction_t create = nullptr, frame = nullptr, builtin = nullptr;
+};
+std::vector<Module> g_mods;
 
 int fail(const char *what, hipError_t e) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -62,21 +67,49 @@ extern "C" {
 
 const char *ref950_last_error(void) { return g_err.c_str(); }
 
+// → handle (>= 0) of the code object, or -1
 int ref950_open(const char *hsaco_path, int device) {
-    TRY(hipSetDevice(device));
-    if (g_mod) return 0;
-    TRY(hipModuleLoad(&g_mod, hsaco_path));
-    TRY(hipModuleGetFunction(&g_create, g_mod, "createScene"));
-    TRY(hipModuleGetFunction(&g_frame, g_mod, "ref950_sample_frame"));
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return -1; }
+    for (size_t i = 0; i < g_mods.size(); i++)
+        if (g_mods[i].path == hsaco_path) return (int)i;
+    Module m;
+    m.path = hsaco_path;
+    if (hipModuleLoad(&m.mod, hsaco_path) != hipSuccess) { g_err = std::string("hipModuleLoad failed: ") + hsaco_path; return -1; }
+    if (hipModuleGetFunction(&m.create, m.mod, "createScene") != hipSuccess ||
+        hipModuleGetFunction(&m.frame, m.mod, "ref950_sample_frame") != hipSuccess ||
+        hipModuleGetFunction(&m.builtin, m.mod, "ref950_probe_builtin") != hipSuccess) { g_err = "kernel lookup failed"; return -1; }
+    g_mods.push_back(m);
+    return (int)g_mods.size() - 1;
+}
+
+// One OpenCL builtin per record, evaluated by ROCm's OpenCL library inside the code object (ref_gfx950_wrap.cl
+// ref950_probe_builtin): in n × 8 floats, out n × 4 floats.
+int ref950_builtin(int handle, int op, const float *in8, size_t n, float *out4) {
+    if (handle < 0 || (size_t)handle >= g_mods.size()) { g_err = "ref950_open first"; return 1; }
+    if (!in8 || !out4 || n == 0 || n > (1u << 26)) { g_err = "bad arguments"; return 1; }
+    Dev din, dout;
+    TRY(din.put(in8, n * 8 * sizeof(float)));
+    TRY(dout.alloc(n * 16));
+    uint32_t nn = (uint32_t)n;
+    void *args[] = {&op, &din.p, &nn, &dout.p};
+    TRY(hipModuleLaunchKernel(g_mods[handle].builtin, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, nullptr, args, nullptr));
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(out4, dout.p, n * 16, hipMemcpyDeviceToHost));
     return 0;
 }
 
 // Linear radiance of samples first .. first+count-1 of every pixel.
 //   out_sum   w*h*4 floats: per pixel the sum over the samples in .xyz and the count in .w
 //   out_last  optional, w*h*4 floats: the frame of the last sample alone (count = 1 → that sample's frame)
-int ref950_render(const rt_scene_desc *d, const float cam[12], const float *table, int w, int h, uint32_t first,
-                  uint32_t count, float *out_sum, float *out_last) {
-    if (!g_mod) { g_err = "ref950_open first"; return 1; }
+// grid_w × grid_h (0 = the whole frame): only the pixels x < grid_w, y < grid_h are launched — the frame's corner at
+// the origin, with the whole frame's width / height in the primary rays and the table index (get_global_id is the
+// pixel coordinate, raytracer.cl:115; a HIP launch cannot give an OpenCL kernel a global offset).  Other pixels stay 0.
+int ref950_render(int handle, const rt_scene_desc *d, const float cam[12], const float *table, int w, int h, uint32_t first,
+                  uint32_t count, int grid_w, int grid_h, float *out_sum, float *out_last) {
+    if (handle < 0 || (size_t)handle >= g_mods.size()) { g_err = "ref950_open first"; return 1; }
+    hipFunction_t g_create = g_mods[handle].create, g_frame = g_mods[handle].frame;
+    if (grid_w <= 0 || grid_w > w) grid_w = w;
+    if (grid_h <= 0 || grid_h > h) grid_h = h;
     if (!d || !cam || !table || w < 1 || h < 1 || !out_sum) { g_err = "bad arguments"; return 1; }
     Dev mats, sph, pla, len, vtx, uv, idx, mesh, mod, scene, dcam, dtab, frame, acc;
     TRY(mats.put(d->materials, (size_t)d->material_count * sizeof(rt_material)));
@@ -100,6 +133,7 @@ int ref950_render(const rt_scene_desc *d, const float cam[12], const float *tabl
     const size_t n = (size_t)w * h;
     TRY(frame.alloc(n * 16));
     TRY(acc.alloc(n * 16));
+    TRY(hipMemset(frame.p, 0, n * 16));
     TRY(hipMemset(acc.p, 0, n * 16));
 
     // createScene(scene, materials, spheres, planes, lenses, vertices, uvs, indices, meshes, models, ObjectCounter)
@@ -113,7 +147,7 @@ int ref950_render(const rt_scene_desc *d, const float cam[12], const float *tabl
         uint32_t sample = first + k;
         void *fargs[] = {&frame.p, &w, &h, &dcam.p, &dtab.p, &scene.p, &null_image, &sample};
         // the reference enqueues global size (W, H) with the runtime's choice of local size (src/raytracer.cpp:137)
-        TRY(hipModuleLaunchKernel(g_frame, (unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), 1, 64, 4, 1, 0, nullptr,
+        TRY(hipModuleLaunchKernel(g_frame, (unsigned)((grid_w + 63) / 64), (unsigned)((grid_h + 3) / 4), 1, 64, 4, 1, 0, nullptr,
                                   fargs, nullptr));
         hipLaunchKernelGGL(acc_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (float4 *)acc.p,
                            (const float4 *)frame.p, n);

@@ -28,3 +28,27 @@ __kernel void ref950_sample_frame(__global float4* out, int width, int height,
     col c = getCol(&r_main, random_buffer, scene, texture, sample);
     out[(size_t)y * (size_t)width + (size_t)x] = (float4)(c, 1.0f);
 }
+
+// One OpenCL builtin per record, as ROCm's OpenCL library defines it (tests compare the HIP kernels' arithmetic
+// policies 1 / 2, rt_debug_builtin, with this bit for bit): in n x 8 floats {a.xyz, b.xyz, t, -}, out n x float4.
+__kernel void ref950_probe_builtin(int op, __global const float* in, uint n, __global float4* out) {
+    uint i = get_global_id(0);
+    if (i >= n) return;
+    __global const float* a = in + 8 * (size_t)i;
+    float3 x = (float3)(a[0], a[1], a[2]), y = (float3)(a[3], a[4], a[5]);
+    float t = a[6];
+    float4 o = (float4)(0.0f);
+    switch (op) {
+        case 0: o.x = dot(x, y); break;
+        case 1: o.xyz = cross(x, y); break;
+        case 2: o.xyz = normalize(x); break;
+        case 3: { o.x = a[0] / a[1]; o.y = 1.0f / a[0]; float3 c = x / t; o.z = c.y; o.w = c.z; } break;
+        case 4: o.x = sqrt(a[0]); break;
+        case 5: o.xyz = mix(x, y, t); break;
+        case 6: o.xyz = min(x, y); break;
+        case 7: o.x = sign(a[0]); break;
+        case 8: o.x = pow(a[0], 5); break;
+        case 9: o.x = as_float((uint)fabs(dot(x, (float3)(123.9898, 348.233, 433.3314)) * 438.5453)); break;   // raytracer.cl:114
+    }
+    out[i] = o;
+}

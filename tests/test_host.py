@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol(built):
     lib = C.CDLL(rt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_header_is_plain_c_and_a_c_program_links(built, tmp_path):
@@ -44,7 +44,7 @@ def test_header_is_plain_c_and_a_c_program_links(built, tmp_path):
                    check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.split() == ["2", "32", "48", "112"]
+    assert out.stdout.split() == ["3", "32", "48", "112"]
 
 
 def test_struct_layouts_match_reference_device_structs():

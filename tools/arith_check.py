@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""tools/arith_check.py [--policies 1,2] [--workloads ...] [--out FILE] — GPU box.
+
+Bit-for-bit distance between the HIP kernels' arithmetic policies (RT_OPT_ARITH 1 / 2, csrc/pt_arith.hpp) and the
+reference's kernel file as ROCm's own OpenCL tool chain builds it for gfx950 (oracle/_ref_gfx950/ref950_nocontract.hsaco
+for policy 1, ref950.hsaco for policy 2): per builtin on random operands, then per pixel-sample on the workloads.
+Prints one JSON object; `identical` must be 1.0 everywhere."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import opencl_raytracing_amd as rt  # noqa: E402
+import oracle as orc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--policies", default="1,2")
+ap.add_argument("--workloads", default="c1,c2,c4small,c5small,all_kinds")
+ap.add_argument("--out", default="")
+ap.add_argument("--samples", type=int, default=4)
+args = ap.parse_args()
+
+HSACO = {1: orc.REF950_HSACO_NOCONTRACT, 2: orc.REF950_HSACO}
+SPECS = {
+    # name: (workload, kwargs, corner grid or None, spp of the fused comparison)
+    "c1": ("c1", dict(width=256, height=256), None, 16),
+    "c2": ("c2", dict(width=1920, height=1080), None, 64),
+    "c2small": ("c2", dict(width=480, height=270), None, 64),
+    "c4small": ("c4", dict(width=480, height=270, n_spheres=2000), None, 16),
+    "c4": ("c4", dict(width=1920, height=1080), (128, 32), 4),           # 100 000 spheres, brute force in the reference
+    "c5small": ("c5", dict(width=480, height=270, segments=24, rings=16), None, 16),
+    "c5": ("c5", dict(width=1920, height=1080), (128, 32), 4),           # 50 000 faces
+    "all_kinds": ("all_kinds", dict(width=320, height=200), None, 16),
+}
+
+
+def builtin_inputs(n, rng):
+    v = rng.standard_normal((n, 8)).astype(np.float32)
+    scale = np.exp2(rng.integers(-12, 12, size=(n, 1))).astype(np.float32)
+    v[:, :7] *= scale
+    # a sprinkle of special operands
+    v[::97, 0] = 0.0
+    v[::101, :3] = 0.0
+    v[::103, 1] = np.float32(1e-30)
+    v[::107, 0] = np.float32(3e38)
+    v[::109, 6] = np.float32(1e-41)
+    return v
+
+
+res = {"policies": {}}
+for pol in [int(p) for p in args.policies.split(",")]:
+    ref = orc.ReferenceGfx950(HSACO[pol])
+    out = {"hsaco": os.path.basename(HSACO[pol]), "builtins": {}, "workloads": {}}
+    rng = np.random.default_rng(7)
+    probe = rt.RayTracer(8, 8, scene=rt.workloads.get("c1", width=8, height=8).scene)
+    probe.setArith(pol)
+    names = ["dot", "cross", "normalize", "divide", "sqrt", "mix", "min", "sign", "pow5", "hash"]
+    for op, name in enumerate(names):
+        v = builtin_inputs(1 << 20, rng)
+        if name in ("sqrt", "pow5"):
+            v[:, 0] = np.abs(v[:, 0])
+        if name == "pow5":
+            v[:, 0] = rng.random(len(v)).astype(np.float32) * 1.2   # 1 - cos of the incident angle
+        if name == "hash":
+            v[:, :3] = rng.standard_normal((len(v), 3)).astype(np.float32)
+        a, b = probe.debugBuiltin(op, v).view(np.uint32), ref.builtin(op, v).view(np.uint32)
+        nan_a, nan_b = np.isnan(a.view(np.float32)), np.isnan(b.view(np.float32))
+        same = (a == b) | (nan_a & nan_b)
+        out["builtins"][name] = {"n": int(len(v)), "identical": float(same.all(axis=1).mean())}
+    probe.close()
+    for name in args.workloads.split(","):
+        wname, kw, grid, spp = SPECS[name]
+        try:
+            wl = rt.workloads.get(wname, **kw)
+        except TypeError:
+            wl = rt.workloads.get(wname, **{k: v for k, v in kw.items() if k in ("width", "height")})
+        if wl.scene.texture_args()[3]:
+            # a textured scene needs an OpenCL image object: strip the texture use by making those materials diffuse
+            out["workloads"][name] = {"skipped": "textured materials need an OpenCL image object"}
+            continue
+        W, H = wl.width, wl.height
+        t = rt.RayTracer(W, H, scene=wl.scene, seed=rt.workloads.SEED)
+        t.setArith(pol)
+        table = t.getRandomTable()
+        gw, gh = grid if grid else (W, H)
+        t0 = time.time()
+
+        def ours(first, count):
+            t.clear()
+            t.renderSamples(wl.camera, first, count)
+            t.sync()
+            return t.readLinear()[:gh, :gw, :3].astype(np.float64) * count
+
+        per_sample, worst = [], None
+        for k in range(args.samples):
+            _, last = ref.render(wl.scene, wl.camera, table, W, H, k, 1, want_last=True, grid=grid)
+            mine = ours(k, 1).astype(np.float32)
+            theirs = last[:gh, :gw, :3]
+            same = (mine.view(np.uint32) == theirs.view(np.uint32)).all(axis=2)
+            per_sample.append(float(same.mean()))
+            if not same.all() and worst is None:
+                ys, xs = np.nonzero(~same)
+                worst = {"sample": k, "n_diff": int((~same).sum()), "first": [int(xs[0]), int(ys[0])],
+                         "ours": mine[ys[0], xs[0]].tolist(), "ref": theirs[ys[0], xs[0]].tolist()}
+        a = ref.render(wl.scene, wl.camera, table, W, H, 0, spp, grid=grid)[:gh, :gw, :3].astype(np.float64) / spp
+        b = ours(0, spp) / spp
+        rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+        out["workloads"][name] = {
+            "frame": "%dx%d" % (W, H), "compared": "%dx%d" % (gw, gh), "spp": spp,
+            "identical_pixel_fraction_per_sample": [round(x, 7) for x in per_sample],
+            "fused_max_rel_dev": float(rel.max()), "fused_pixels_within_1e-4": float((rel <= 1e-4).mean()),
+            "walk_overflow": t.walkOverflow(), "first_mismatch": worst, "seconds": round(time.time() - t0, 1)}
+        print(name, pol, out["workloads"][name], file=sys.stderr, flush=True)
+        t.close()
+    res["policies"][str(pol)] = out
+txt = json.dumps(res, indent=1)
+print(txt)
+if args.out:
+    open(args.out, "w").write(txt + "\n")
