@@ -1,38 +1,49 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X path tracer.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5] [--scaling strong|weak]
+    python bench.py --gpus N --steps K --warmup W
+                    [--workload c2|c3|c4|c5] [--size WxH] [--spp S] [--scaling weak|strong]
+                    [--arith rocm-opencl|rocm-opencl-nocontract|ieee]
 
-Metric (BASELINE.json): Msamples/s (pixel-samples = camera paths per second), with the roofline
-fraction of the dominant kernel.  One *step* = one pass of the hot path over one frame: clear, ONE
-fused trace call over every pixel-sample of the frame (pt_prefix + pt_samples_q / pt_samples_w),
-resolve to the gamma image and — for N > 1 — the exchange of the tile-sharded radiance buffer to
-rank 0 over RCCL.  Scene, camera block and random table are resident in HBM before the timed region.
+Metric (BASELINE.json): Msamples/s (pixel-samples = camera paths per second) and the % of the HBM roofline; the
+roofline that actually binds (VALU issue) rides along.  One *step* = one pass of the hot path over one frame: clear,
+the fused trace call(s) over every pixel-sample of the frame (pt_prefix + pt_samples_q / pt_samples_w), resolve to the
+gamma image and — for N > 1 — the exchange of the tile-sharded radiance buffer to rank 0 over RCCL.  Scene, camera
+block and random table are resident in HBM before the timed region.
 
-Workload per N (BASELINE.json `configs`):
-  N = 1        C2, the configuration the metric is quoted on: 8 spheres + plane, 1920x1080, 64 spp.
-  N = 2, 4, 8  C4 by default — 100 000 spheres + plane, 1920x1080, 64 spp, "tile-sharded 2/4/8 x MI355X":
-               STRONG scaling, the same frame cut into 8x8 tiles interleaved over the ranks
-               (`--workload c5` is BASELINE's 8-GPU configuration).  The line also carries the same
-               workload's single-GPU step time, measured by rank 0 in the same run outside the timed
-               region, so that the speed-up can be read from one line.
-  --scaling weak   the round-1 form: C2 with 64 x N samples per pixel, per-GPU work fixed — issued as N
-               calls of 64 samples, so every rank runs the very kernels of the N = 1 line.
+Workload: ONE workload along the whole N curve — C2 by default, the configuration the metric is quoted on
+(8 spheres + plane, 1920x1080, 64 spp).
+  C2 / C3 (frames of milliseconds)  WEAK scaling: every pixel gets 64 x N samples, issued as N fused calls of 64, the
+            frame's 8x8 tiles interleaved over the ranks — each GPU traces the pixel-samples of one N = 1 frame with
+            the very kernels of the N = 1 line, then the packed tiles meet on rank 0.
+  C4 / C5 (BASELINE's tile-sharded configurations, frames of 0.1 ... 1 s)  STRONG scaling: the same frame cut over the ranks.
+Every N > 1 line also carries the same workload's single-GPU step (rank 0 alone, same run, untimed leg) and
+`speedup_vs_1gpu_same_workload`, so the curve can be read from one line.
+A plain `python bench.py --gpus N` (N > 1, no torchrun environment) starts its own ranks:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process whose
+JSON line and return code are relayed.
+
+`--arith` selects the arithmetic policy that is timed (csrc/pt_arith.hpp): `rocm-opencl` (default) computes, bit for
+bit per pixel-sample, what the reference's kernel file computes when ROCm's own OpenCL tool chain builds it with default
+options for this chip; `ieee` is the plain-IEEE contract the CPU oracle restates.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-  "roofline"     VALU issue: the kernels are bound by vector-instruction issue, not by HBM.
-                 achieved = issue cycles of the dominant kernel per launch (rocprofv3 SQ_INSTS_VALU_* class
-                 counts x the issue cost of each class measured on this chip, profiles/valu_mix.json)
-                 / that kernel's HIP-event duration measured live here; peak = 1024 SIMDs x 2.4 GHz.
-                 hbm_frac (counter bytes / time / 8 TB/s) and the round-1 algorithmic-bytes figure
-                 (labelled non-physical) ride along.
-  "parity"       untimed: probes of the measured configuration AND a crop of the resolved timed frame
-                 against the oracle.
+  "roofline"     bound "valu": the kernels are bound by vector-instruction issue, not by HBM.  achieved =
+                 issue cycles of the dominant kernel per launch (rocprofv3 SQ_INSTS_VALU_* class counts x the issue
+                 cost of each class measured on this chip, profiles/valu_mix.json) / that kernel's HIP-event duration
+                 measured live here; peak = 1024 SIMDs x 2.4 GHz.  hbm_frac (counter bytes / time / 8 TB/s = the
+                 metric's "% HBM roofline"), alg_flop_frac (the reference's logical flops / time / 157.3 TFLOP/s) and the
+                 round-1 algorithmic-bytes figure (labelled non-physical) ride along.
+  "parity"       untimed: `real_opencl` — the timed policy against the reference's gfx950 OpenCL code object, per
+                 pixel-sample bit for bit and the timed frame within 1e-4; `cpu_oracle_ieee` — policy 0 against the
+                 CPU oracle (probes bit for bit, a frame crop within 1e-4); `walk_overflow` must be 0.
   "cpu_baseline" the oracle (CPU restatement of the reference kernel) on this host's cores, bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,20 +51,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3   # vector fp32 (not MFMA): 256 CUs x 128 lanes x 2 flop x 2.4 GHz
 SIMDS = 1024               # 256 CUs x 4 SIMD-32
 PEAK_CLOCK_GHZ = 2.4
 WORKLOAD_DESC = {
     "c2": "C2 Cornell-style: 8 spheres + 1 plane",
     "c3": "C3 textured 12-triangle cube + 4 spheres",
     "c4": "C4 100k random spheres + plane",
-    "c5": "C5 50k-triangle dielectric mesh",
+    "c5": "C5 50k-triangle dielectric OBJ mesh",
 }
+ARITH = {"ieee": 0, "rocm-opencl-nocontract": 1, "rocm-opencl": 2}
 # dominant kernel of one fused trace call, per workload (what `roofline` prices), and its first stage
 KERNELS = {"c2": ("pt_samples_q<false, false, 0", "pt_prefix<false, false>"),
            "c3": ("pt_samples_q<false, false, 1", "pt_prefix<false, false>"),
            "c4": ("pt_samples_q<false, true, 0", "pt_prefix<false, true>"),
            "c5": ("pt_samples_w<false>", "pt_prefix<false, true>")}
-CROP = {"c2": (900, 330, 32, 16), "c3": (930, 300, 32, 16), "c4": (960, 270, 8, 4), "c5": (1900, 900, 4, 2)}
+# crop of the frame compared with the CPU oracle (fractions of the frame: x, y; then width, height in pixels)
+CROP = {"c2": (0.469, 0.306, 32, 16), "c3": (0.484, 0.278, 32, 16), "c4": (0.5, 0.25, 8, 4), "c5": (0.495, 0.417, 4, 2)}
+# corner of the frame the reference's OpenCL build renders for the parity leg (it searches by brute force)
+REAL_OPENCL_CORNER = {"c2": None, "c3": None, "c4": (64, 16), "c5": (32, 8)}
+# flops of the reference's routines, per counter of rt_counters: hitSphere miss path 17; hitPlane
+# 11; hitLens 40; hitTriangle 27 to its last reject + 25 more when it hits (uv, point, normal); per hit bounce 40
+# (point, normal, material, mixCol); rayScatter 15 (+ normalize); the dielectric branch 30; primary ray 25
+FLOPS = {"t_sphere": 17, "t_plane": 11, "t_lens": 40, "t_tri": 27, "h_tri": 25, "h_bounce": 40, "n_scatter": 15,
+         "n_dielectric": 30, "samples": 25}
 
 
 def host_cores():
@@ -74,6 +95,27 @@ def source_digest():
     was measured on."""
     import __graft_entry__ as g
     return g.device_source_digest()
+
+
+def profile_key(workload, width, height, spp):
+    return "%s@%dx%dx%d" % (workload, width, height, spp)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a child process (never exec:
+    this process may already hold the GPU) and relay its one JSON line and its return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    print("[bench] --gpus %d without a torchrun environment: starting the ranks myself\n[bench]   %s" %
+          (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    return p.returncode
 
 
 def cpu_baseline(wl, table, budget_s=20.0):
@@ -128,11 +170,12 @@ def cpu_baseline(wl, table, budget_s=20.0):
     wall = run(regions, spp_s)
     samples = nb * rows * cw_s * spp_s
     return {"value": round(samples / wall / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "arith": "ieee (the oracle's contract)",
             "sample": "%d band(s) of %d rows x %d columns of the %dx%d frame, %d of %d spp = %.3f M pixel-samples, "
                       "%.1f s wall" % (nb, rows, cw_s, W, H, spp_s, spp, samples / 1e6, wall)}
 
 
-def roofline(workload, main_ms, first_ms, call_ms, alg_bytes, share=1.0, valid=True):
+def roofline(workload, key, arith, main_ms, first_ms, call_ms, counters, share=1.0, valid=True):
     """VALU-issue roofline of the dominant kernel from profiles/valu_mix.json (class counts per launch x
     measured issue costs) and the kernel's live HIP-event time; see tools/summarize_profile.py."""
     peak = SIMDS * PEAK_CLOCK_GHZ                                   # G issue cycles / s
@@ -146,14 +189,15 @@ def roofline(workload, main_ms, first_ms, call_ms, alg_bytes, share=1.0, valid=T
     mix = None
     if os.path.isfile(path):
         try:
-            mix = json.load(open(path)).get(workload)
+            mix = json.load(open(path)).get(key)
         except Exception:
             mix = None
     main_key, first_key = KERNELS[workload]
+    ns = "pt_a%d::" % ARITH[arith]
     kern = None
-    if mix:
+    if mix and mix.get("arith") == arith:
         for name, k in mix.get("kernels", {}).items():
-            if name.startswith(main_key):
+            if name.startswith(ns + main_key):
                 kern, out["kernel"] = k, name
     t = main_ms * 1e-3
     if kern and not valid:
@@ -183,13 +227,91 @@ def roofline(workload, main_ms, first_ms, call_ms, alg_bytes, share=1.0, valid=T
             out["traffic"] = int(hbm)
             out["hbm_frac"] = round(hbm / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     elif "note" not in out:
-        out["note"] = "profiles/valu_mix.json has no entry for this workload: run tools/profile.sh + tools/summarize_profile.py"
+        out["note"] = ("profiles/valu_mix.json has no entry '%s' for arithmetic '%s': run tools/profile.sh + "
+                       "tools/summarize_profile.py" % (key, arith))
+    # work / peak: the reference's logical flops (its brute-force searches included) over the call time.  For a workload
+    # that runs through a BVH (C4, C5) most of these flops are never executed: a figure above 1 says "algorithmically
+    # avoided", not "faster than the chip".
+    flops = float(sum(FLOPS[k] * getattr(counters, k) for k in FLOPS))
+    out["alg_flop_frac"] = {"value": round(flops / (call_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                            "algorithmic_flops_per_launch": int(flops), "peak_tflops": FP32_PEAK_TFLOPS,
+                            "note": "reference's logical fp32 flops (SURVEY 8d item 3: 17 per sphere test, 11 plane, 27 + 25 "
+                                    "triangle, 40 per hit bounce, 15 scatter, 30 dielectric, 25 per primary ray) / call time / "
+                                    "vector-fp32 peak" + ("; brute-force work a BVH skips is counted: not a physical rate"
+                                                          if workload in ("c4", "c5") else "")}
     # round 1's figure, kept for continuity: the REFERENCE kernel's logical traffic (every primitive struct it
     # would have dereferenced) over the call time.  The scene lives in SGPRs / L2, so these bytes never move:
     # not a physical rate, and not bounded by 1.
+    alg_bytes = counters.algorithmic_bytes()
     out["alg_hbm_frac"] = {"value": round(alg_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "algorithmic_bytes_per_launch": int(alg_bytes),
                            "note": "non-physical: reference's brute-force logical bytes / time / 8 TB/s (SURVEY 8d)"}
+    return out
+
+
+def parity_leg(rt, np, tracer, wl, workload, spp, arith, table, note):
+    """Untimed.  (1) the timed policy against the reference's gfx950 OpenCL code object (the pin to a real OpenCL
+    build): samples 0 and 1 of the compared region bit for bit, the timed frame's linear radiance within 1e-4;
+    (2) policy 0 against the CPU oracle: probes bit for bit, a crop of a frame within 1e-4."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc_mod
+    W, H = wl.width, wl.height
+    out = {"arith_timed": arith, "real_opencl": None, "cpu_oracle_ieee": None}
+    timed_linear = tracer.readLinear()[..., :3].astype(np.float64)     # the last timed step's accumulator / count
+    # ---- (1)
+    hs = {"rocm-opencl": orc_mod.REF950_HSACO, "rocm-opencl-nocontract": orc_mod.REF950_HSACO_NOCONTRACT,
+          "ieee": orc_mod.REF950_HSACO}[arith]
+    if wl.scene.texture_args()[3]:
+        out["real_opencl"] = {"skipped": "t_textured materials need an OpenCL image object, which a HIP process cannot create "
+                                         "(raytracer.cl:105-107 stays unpinned; tests/test_gpu_ref950.py compares the untextured scene)"}
+    elif not orc_mod.ReferenceGfx950.available(hs):
+        out["real_opencl"] = {"skipped": "oracle/_ref_gfx950 (the reference built by ROCm's OpenCL tool chain) is not on this machine"}
+    else:
+        note("parity: against the reference's gfx950 OpenCL build (%s)" % os.path.basename(hs))
+        ref = orc_mod.ReferenceGfx950(hs)
+        grid = REAL_OPENCL_CORNER[workload]
+        gw, gh = grid if grid else (W, H)
+        same = []
+        for k in (0, 1):
+            _, last = ref.render(wl.scene, wl.camera, table, W, H, k, 1, want_last=True, grid=grid)
+            tracer.clear()
+            tracer.renderSamples(wl.camera, k, 1)
+            tracer.sync()
+            mine = tracer.readLinear()[:gh, :gw, :3]
+            same.append(float((mine.view(np.uint32) == last[:gh, :gw, :3].view(np.uint32)).all(axis=2).mean()))
+        a = ref.render(wl.scene, wl.camera, table, W, H, 0, spp, grid=grid)[:gh, :gw, :3].astype(np.float64) / spp
+        b = timed_linear[:gh, :gw]
+        rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+        out["real_opencl"] = {
+            "checker": "oracle/_ref_gfx950/" + os.path.basename(hs) + " (kernels/raytracer.cl built by ROCm's OpenCL tool chain, ROCm's builtin library)",
+            "region": "whole frame" if not grid else "corner %dx%d of the frame" % (gw, gh),
+            "pixel_samples_bit_identical_samples_0_1": same,
+            "timed_frame_max_rel_dev": float(rel.max()), "timed_frame_pixels_within_1e-4": float((rel <= 1e-4).mean()),
+            "lit_fraction": float((a.sum(axis=2) > 0).mean()),
+            "ok": (arith == "ieee") or (min(same) == 1.0 and float(rel.max()) <= 1e-4),
+            **({"note": "policy ieee is the CPU oracle's contract and does not claim bit identity with an OpenCL build: distance only"}
+               if arith == "ieee" else {})}
+    # ---- (2)
+    note("parity: policy ieee against the CPU oracle")
+    orc = orc_mod.Oracle()
+    tracer.setArith("ieee")
+    rng = np.random.RandomState(1)
+    n = 64 if workload in ("c4", "c5") else 2000
+    xs, ys, ss = rng.randint(0, W, n), rng.randint(0, H, n), rng.randint(0, spp, n)
+    got = tracer.traceSamples(wl.camera, xs, ys, ss)
+    exp, _ = orc.samples(wl.scene, wl.camera, table, W, H, xs, ys, ss)
+    bit = int((got.view(np.uint32) == exp.view(np.uint32)).all(axis=1).sum())
+    fx, fy, cw, ch = CROP[workload]
+    x0, y0 = min(int(fx * W), W - cw), min(int(fy * H), H - ch)
+    frame = tracer.renderFrame(wl.camera, spp)
+    ref_img, _ = orc.render(wl.scene, wl.camera, table, W, H, 2, count=spp, region=(x0, y0, cw, ch), threads=host_cores())
+    a, b = frame[y0:y0 + ch, x0:x0 + cw], ref_img[y0:y0 + ch, x0:x0 + cw]
+    dev = float((np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max())
+    out["cpu_oracle_ieee"] = {"checker": "oracle/pt_oracle.c", "probes": n, "bit_exact": bit, "frame_crop": [x0, y0, cw, ch],
+                              "crop_max_rel_dev": dev, "crop_ok": dev <= 1e-4,
+                              "crop_lit_fraction": float((b[..., :3].sum(-1) > 0).mean())}
+    tracer.setArith(arith)
+    out["walk_overflow"] = tracer.walkOverflow()
     return out
 
 
@@ -198,11 +320,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOAD_DESC),
-                    help="default: c2 at N = 1, c4 (BASELINE's tile-sharded configuration) at N > 1")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC),
+                    help="default c2, the configuration the metric is quoted on — at every N")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
-                    help="N > 1: strong (default) = the same frame sharded; weak = C2 with 64 x N spp in N calls")
+                    help="N > 1: auto = weak for c2 / c3 (64 x N spp in N calls of 64), strong for c4 / c5 (the same frame sharded)")
+    ap.add_argument("--size", default="", metavar="WxH", help="override the frame size, e.g. 1920x1080")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--arith", default="rocm-opencl", choices=sorted(ARITH),
+                    help="arithmetic policy of the timed kernels (csrc/pt_arith.hpp)")
     ap.add_argument("--workload-arg", action="append", default=[], metavar="KEY=INT",
                     help="rehearsals only: override a generator argument of the workload, e.g. n_spheres=20000")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
@@ -210,8 +335,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-single-gpu-reference", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg")
+    ap.add_argument("--no-arith-variants", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline leg (N > 1: a quarter)")
     args = ap.parse_args()
+
+    # a plain `python bench.py --gpus N`: start the ranks as a child BEFORE anything touches torch or HIP
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -223,20 +353,28 @@ def main():
         sys.exit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
     rank, world, local = dist_mod.init_process_group()
     if world != args.gpus:
-        sys.exit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" %
+        sys.exit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or plain)" %
                  (args.gpus, world, args.gpus))
     device = local % torch.cuda.device_count()   # == local on a full node; rehearsals may oversubscribe a GPU
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
-    scaling = args.scaling if args.scaling != "auto" else "strong"
-    workload = args.workload or ("c2" if world == 1 or scaling == "weak" else "c4")
+    workload = args.workload
+    scaling = args.scaling if args.scaling != "auto" else ("weak" if workload in ("c2", "c3") else "strong")
     wl_args = {k: int(v) for k, v in (a.split("=", 1) for a in args.workload_arg)}
+    if args.size:
+        w_, h_ = args.size.lower().split("x")
+        wl_args.update(width=int(w_), height=int(h_))
     wl = rt.workloads.get(workload, **wl_args)
+    generator_overridden = any(k not in ("width", "height") for k in wl_args)
     base_spp = args.spp or wl.spp
+    wl.spp = base_spp
     spp = base_spp * world if scaling == "weak" else base_spp
     chunk = base_spp                                 # samples per fused call: the kernels of the N = 1 line
+    key = profile_key(workload, wl.width, wl.height, base_spp)
     tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
+    tracer.setArith(args.arith)
+    tracer.resetCounters()
     shard = dist_mod.GpuShard(tracer, rank, world, chunk=chunk)
     renderer = dist_mod.ShardedRenderer(shard, rank, world, exchange=args.exchange)
     table = tracer.getRandomTable() if rank == 0 else None
@@ -253,15 +391,13 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    # algorithmic bytes of one launch: exact work counters from the counting build (untimed)
-    note("counting pass (%s, %d rank(s), %s scaling)" % (workload, world, scaling))
+    # algorithmic work of one launch: exact work counters from the counting build (untimed)
+    note("counting pass (%s, %s, %d rank(s), %s scaling, arithmetic %s)" % (workload, key, world, scaling, args.arith))
     tracer.enableCounters(True)
-    tracer.resetCounters()
     step()
     tracer.sync()
     cn = tracer.counters()
     tracer.enableCounters(False)
-    alg_bytes = cn.algorithmic_bytes()
     my_samples = cn.samples
 
     note("warmup + %d timed steps" % args.steps)
@@ -287,18 +423,19 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
     wall_max, total_samples = float(t.item()), float(s.item())
 
-    # strong scaling: the same workload on ONE GPU, by rank 0, outside the timed region
+    # the same workload on ONE GPU, by rank 0, outside the timed region: the frame of the N = 1 line
     single = None
-    if world > 1 and scaling == "strong" and not args.no_single_gpu_reference:
+    if world > 1 and not args.no_single_gpu_reference:
         if rank == 0:
             note("single-GPU reference of the same workload (untimed leg)")
             solo = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
+            solo.setArith(args.arith)
             n_solo = 3 if workload in ("c4", "c5") else 10
-            solo.renderFrameOnDevice(wl.camera, spp)
+            solo.renderFrameOnDevice(wl.camera, base_spp)
             solo.sync()
             t1 = time.perf_counter()
             for _ in range(n_solo):
-                solo.renderFrameOnDevice(wl.camera, spp)
+                solo.renderFrameOnDevice(wl.camera, base_spp)
             solo.sync()
             single = (time.perf_counter() - t1) / n_solo * 1e3
             solo.close()
@@ -307,55 +444,57 @@ def main():
     if rank == 0:
         ms_per_step = wall_max / args.steps * 1e3
         value = total_samples * args.steps / wall_max / 1e6
+        roof = roofline(workload, key, args.arith, float(np.mean(main_ms)), float(np.mean(first_ms)), call_ms, cn,
+                        share=my_samples / float(wl.width * wl.height * base_spp) / (spp // chunk),
+                        valid=not generator_overridden)
         out = {
-            "metric": "Msamples/sec (rays/sec) at %dx%d, %d spp; fraction of the roofline that binds (VALU issue)" %
-                      (wl.width, wl.height, spp),
+            "metric": "Msamples/sec (rays/sec) at %d×%d, %d spp; %% HBM roofline" % (wl.width, wl.height, spp),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "hbm_roofline_pct": round(100.0 * roof["hbm_frac"], 3) if roof.get("hbm_frac") is not None else None,
+            "arith": args.arith,
             "config": {"workload": "%s, %dx%d, %d spp" % (WORKLOAD_DESC[workload], wl.width, wl.height, spp),
                        "width": wl.width, "height": wl.height, "spp_per_call": chunk, "spp_total": spp,
                        "sharding": "8x8 tiles interleaved over %d rank(s)" % world +
                                    ("; %s of the packed radiance tiles to rank 0 over RCCL" % args.exchange if world > 1 else ""),
                        "pixel_samples_per_step": int(total_samples), "seed": hex(rt.workloads.SEED),
+                       "profile_key": key,
+                       "arithmetic": "%s (RT_OPT_ARITH %d, csrc/pt_arith.hpp)" % (args.arith, ARITH[args.arith]),
                        **({"workload_overrides": wl_args} if wl_args else {})},
-            "roofline": roofline(workload, float(np.mean(main_ms)), float(np.mean(first_ms)), call_ms, alg_bytes,
-                                 share=my_samples / float(wl.width * wl.height * base_spp) / (spp // chunk),
-                                 valid=not wl_args and not args.spp),
+            "roofline": roof,
             "kernel_ms_min_max": [round(min(ev_ms), 4), round(max(ev_ms), 4)],
             "bounces_per_sample": round(cn.bounces / max(cn.samples, 1), 3),
         }
         if single is not None:
-            out["single_gpu_same_workload"] = {"ms_per_step": round(single, 4),
-                                               "value": round(total_samples / (single * 1e-3) / 1e6, 2),
-                                               "speedup": round(single / ms_per_step, 3),
-                                               "note": "rank 0 alone, same frame, same run, outside the timed region"}
+            # strong: the same frame → time ratio; weak: N frames' worth of pixel-samples against one → throughput ratio
+            speedup = single / ms_per_step * (world if scaling == "weak" else 1)
+            out["single_gpu_same_workload"] = {
+                "ms_per_step": round(single, 4),
+                "value": round(wl.width * wl.height * base_spp / (single * 1e-3) / 1e6, 2),
+                "note": "rank 0 alone, the %d-spp frame of the N = 1 line, same run, outside the timed region" % base_spp}
+            out["speedup_vs_1gpu_same_workload"] = round(speedup, 3)
+        if world == 1 and not args.no_arith_variants:
+            # the same frame under the other arithmetic policies (5 steps each, untimed leg): what the policy costs
+            variants = {}
+            for name in sorted(ARITH, key=ARITH.get):
+                tracer.setArith(name)
+                for _ in range(6):
+                    step()
+                tracer.sync()
+                f_ms, m_ms = tracer.stageMsHistory(5)
+                variants[name] = {"first_stage_ms": round(float(np.mean(f_ms)), 4), "kernel_ms": round(float(np.mean(m_ms)), 4)}
+            tracer.setArith(args.arith)
+            step()                      # the accumulator holds a frame of the timed policy again
+            tracer.sync()
+            out["arith_variants"] = variants
         if world == 1 and not args.no_parity_check:
-            # untimed sanity leg: the configuration just measured computes the reference's radiance.
-            # (1) per pixel-sample probes, bit for bit; (2) a crop of the RESOLVED TIMED FRAME (what pt_prefix +
-            # the sample kernel left in the image buffer) against the oracle's progressive image, 1e-4 relative.
-            note("parity: probes + crop of the timed frame")
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            from oracle import Oracle
-            orc = Oracle()
-            rng = np.random.RandomState(1)
-            n = 64 if workload in ("c4", "c5") else 2000
-            xs, ys, ss = rng.randint(0, wl.width, n), rng.randint(0, wl.height, n), rng.randint(0, spp, n)
-            got = tracer.traceSamples(wl.camera, xs, ys, ss)
-            exp, _ = orc.samples(wl.scene, wl.camera, table, wl.width, wl.height, xs, ys, ss)
-            same = int((got.view(np.uint32) == exp.view(np.uint32)).all(axis=1).sum())
-            x0, y0, cw, ch = CROP[workload]
-            frame = renderer.image()                  # the last timed step's image
-            ref, _ = orc.render(wl.scene, wl.camera, table, wl.width, wl.height, 2, count=spp, region=(x0, y0, cw, ch),
-                                threads=host_cores())
-            a, b = frame[y0:y0 + ch, x0:x0 + cw], ref[y0:y0 + ch, x0:x0 + cw]
-            dev = float((np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max())
-            out["parity"] = {"probes": n, "bit_exact": same, "checker": "oracle/pt_oracle.c",
-                             "timed_frame_crop": [x0, y0, cw, ch], "crop_max_rel_dev": dev, "crop_ok": dev <= 1e-4,
-                             "crop_lit_fraction": float((b[..., :3].sum(-1) > 0).mean())}
-        if not args.no_cpu_baseline and world == 1:
+            out["parity"] = parity_leg(rt, np, tracer, wl, workload, spp, args.arith, table, note)
+        else:
+            out["walk_overflow"] = tracer.walkOverflow()
+        if not args.no_cpu_baseline:
             note("cpu baseline")
-            out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(wl, table, args.cpu_budget if world == 1 else args.cpu_budget / 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -6,7 +6,8 @@ RayTracer / SceneCreator / Camera API over the C ABI of librt_amd.so
 """
 from . import _abi, workloads  # noqa: F401
 from .camera import Camera  # noqa: F401
-from .raytracer import LIB_PATH, RayTracer, RtError, check_accel, load_library, make_random_table  # noqa: F401
+from .raytracer import (ARITH_IEEE, ARITH_NAMES, ARITH_ROCM_OCL, ARITH_ROCM_OCL_NOCONTRACT, LIB_PATH, RayTracer,  # noqa: F401
+                        RtError, check_accel, load_library, make_random_table)
 from .scene import SceneCreator, SceneError  # noqa: F401
 
 __all__ = ["Camera", "RayTracer", "RtError", "SceneCreator", "SceneError", "workloads", "load_library",

@@ -224,7 +224,7 @@ class RayTracer:
     def setShard(self, rank, world, tile_w=8, tile_h=8):
         self._check(self._lib.rt_set_shard(self._ctx, rank, world, tile_w, tile_h))
 
-    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES = 1, 2, 3, 4, 5
+    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH = 1, 2, 3, 4, 5, 6
 
     def setOption(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, int(value)))

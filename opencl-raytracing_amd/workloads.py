@@ -226,6 +226,17 @@ def shipped_like(width=1200, height=800, spp=16):
                     "spheres + plane + lens + 2 textured cubes (assets/scenes/all_kinds.scene)")
 
 
+def untextured(wl):
+    """The same workload with every t_textured material turned into t_diffuse and no texture array: the reference's
+    real OpenCL build (oracle/_ref_gfx950) can only be driven without an OpenCL image object, and everything but the
+    texel fetch (raytracer.cl:105-107) — lenses, small meshes by face scan, uv interpolation — is still exercised."""
+    wl.scene.materials["type"][wl.scene.materials["type"] == _abi.T_TEXTURED] = _abi.T_DIFFUSE
+    wl.scene.textures = None
+    wl.scene.texture_paths = []
+    wl.name += "_untextured"
+    return wl
+
+
 _REGISTRY = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "all_kinds": shipped_like}
 
 

@@ -624,3 +624,74 @@ def test_mesh_bvh_small_and_large_worlds(scale):
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert (frames[1][..., :3].sum(-1) > 0).mean() > 0.2
     t.close()
+
+
+
+# ---- frame-scale regressions of both BVHs on the REAL geometry of C4 / C5 ----------------------
+def _accel_frames(wl, spp, modes):
+    t = rt.RayTracer(wl.width, wl.height, scene=wl.scene, seed=cases.SEED)
+    t.resetCounters()
+    out = []
+    for accel in modes:
+        t.setOption(t.OPT_ACCEL, accel)
+        t.clear()
+        t.renderSamples(wl.camera, 0, spp)
+        t.sync()
+        lin = t.readLinear().copy()
+        t.render(wl.camera)
+        out.append((lin, t.transferImage().copy()))
+    assert t.walkOverflow() == 0
+    t.close()
+    return out
+
+
+def test_mesh_bvh_full_frame_on_the_real_c5_mesh():
+    """C5's actual mesh (50 000 faces, 200 x 126 uv-sphere: small faces, its own grazing regime), the whole 1920x1080
+    frame, 2 spp: the reference's face scan (RT_OPT_ACCEL 0) against the mesh BVH + walk slices — accumulators and the
+    compat image bit-equal.  The culling margins are derived bounds + 9 %; this is their frame-scale check."""
+    wl = rt.workloads.get("c5", width=1920, height=1080)
+    assert len(wl.scene.indices) // 3 == 50000
+    (a_lin, a_img), (b_lin, b_img) = _accel_frames(wl, 2, (0, 1))
+    assert np.array_equal(a_lin.view(np.uint32), b_lin.view(np.uint32))
+    assert np.array_equal(a_img.view(np.uint32), b_img.view(np.uint32))
+    assert (a_lin[..., :3].sum(axis=2) > 0).mean() > 0.2
+
+
+def test_sphere_bvh_full_frame_on_c4_with_100000_spheres():
+    """C4 as benchmarked (100 000 spheres), the whole 1920x1080 frame, 1 spp: brute force against the sphere BVH."""
+    wl = rt.workloads.get("c4", width=1920, height=1080)
+    assert len(wl.scene.spheres) == 100000
+    (a_lin, a_img), (b_lin, b_img) = _accel_frames(wl, 1, (0, 2))
+    assert np.array_equal(a_lin.view(np.uint32), b_lin.view(np.uint32))
+    assert np.array_equal(a_img.view(np.uint32), b_img.view(np.uint32))
+
+
+@pytest.mark.parametrize("spp", [1, 64])
+def test_live_list_far_shorter_than_the_grid(spp, oracle, table):
+    """The sample kernels' grids are sized for "every pixel is live"; live_take must hand nothing to the waves beyond
+    the list.  An all-sky frame (no live pixel at all) and a frame with a single tiny diffuse sphere (a handful of
+    live pixels out of 65 536) — against the oracle, through queue kernel and fixed-lane kernel."""
+    for n_spheres in (0, 1):
+        s = rt.SceneCreator()
+        s.addMaterial(rt._abi.T_DIFFUSE, (0.9, 0.5, 0.2), 1)
+        s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)
+        s.addSphere((0, -300, 0), 100, 1)               # the light, behind the camera's view
+        if n_spheres:
+            s.addSphere((0.0, 0.0, 100.0), 0.3, 0)      # on the axis: pixel (128, 128) looks straight at it, its neighbours
+                                                        # (0.45 units apart at that distance) pass beside it
+        cam = rt.Camera(60, 1.0, (0, 0, 0), 0.0, 0.0).transferData()
+        W = H = 256
+        t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
+        t.resetCounters()
+        ref, _ = oracle.render(s, cam, table, W, H, 2, count=spp, threads=8)
+        for queue in (1, 0):
+            t.setOption(t.OPT_SAMPLE_QUEUE, queue)
+            img = t.renderFrame(cam, spp)
+            err = np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)
+            assert err.max() <= 1e-4, (n_spheres, queue, err.max())
+        lit = int((ref[..., :3].sum(axis=2) > 0).sum())
+        assert lit == (0 if n_spheres == 0 or spp == 1 and ref[128, 128, :3].sum() == 0 else 1), lit
+        if n_spheres and spp == 64:
+            assert ref[128, 128, :3].sum() > 0      # the one live pixel: some of its 64 diffuse bounces reach the light
+        assert t.walkOverflow() == 0
+        t.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tools/isa_stats.py [kernel-substring ...] — static ISA statistics of the shipped gfx950 kernels.
+"""tools/isa_stats.py [--arith K] [kernel-substring ...] — static ISA statistics of the shipped gfx950 kernels.
 
-Compiles csrc/rt_amd.hip for the device only (-S, the flags of __graft_entry__.HIP_FLAGS) and prints, per
+Compiles csrc/pt_kernels.hip for the device only (-S, the flags of __graft_entry__ for arithmetic policy K = 0 | 1 | 2,
+default 2 = rocm-opencl, the policy bench.py times; ISA_ARITH in the environment does the same) and prints, per
 kernel: VGPRs / SGPRs / scratch bytes / spilled VGPRs from the code-object metadata and the static opcode
 histogram grouped into the issue-cost classes measured by tools/valu_microbench.hip
 (profiles/r02_valu_microbench.md).  --json dumps everything for bench.py / profile summaries."""
@@ -69,16 +70,24 @@ def group_costs(ops):
     return {g: (n[g], cyc[g] / n[g]) for g in n}
 
 
-def device_asm(force=False):
+def default_arith():
+    for i, a in enumerate(sys.argv):
+        if a == "--arith" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+    return int(os.environ.get("ISA_ARITH", "2"))
+
+
+def device_asm(force=False, arith=None):
     import __graft_entry__ as g
+    arith = default_arith() if arith is None else int(arith)
     extra = os.environ.get("ISA_EXTRA_FLAGS", "").split()   # e.g. ISA_EXTRA_FLAGS="-DPT_Q_BLOCK_WAVES=1" for a variant
     tag = ("_" + "_".join(e.lstrip("-D").replace("=", "") for e in extra)) if extra else ""
-    out = os.path.join(ROOT, "build", "rt_amd_gfx950%s.s" % tag)
+    out = os.path.join(ROOT, "build", "pt_kernels_a%d_gfx950%s.s" % (arith, tag))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     srcs = g.hip_sources()
     if force or not os.path.isfile(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
-        flags = [f for f in g.HIP_FLAGS if f not in ("-shared", "-fPIC")]
-        subprocess.check_call([g.HIPCC] + flags + extra + ["--cuda-device-only", "-S", srcs[0], "-o", out],
+        flags = [f for f in g.HIP_FLAGS if f not in ("-shared", "-fPIC")] + g.POLICY_FLAGS[arith]
+        subprocess.check_call([g.HIPCC] + flags + extra + ["--cuda-device-only", "-S", srcs[1], "-o", out],
                               stderr=subprocess.DEVNULL)
     return out
 
@@ -135,7 +144,7 @@ def summarize(k):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--arith"]
     ks = kernels(device_asm("--force" in sys.argv))
     if "--json" in sys.argv:
         print(json.dumps({k["demangled"]: dict(summarize(k), vgpr=k["vgpr"], sgpr=k["sgpr"], scratch=k["scratch"],

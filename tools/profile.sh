@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-parity-check $@"
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-parity-check --no-arith-variants $@"
 echo "== kernel trace + stats" && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_CYCLES" \
@@ -18,7 +18,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   echo "== pmc $pass"
-  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check "$@" > $OUT/bench_pmc_$name.json 2> $OUT/pmc_$name.err || { tail -5 $OUT/pmc_$name.err; echo "pass failed: $pass"; }
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check --no-arith-variants "$@" > $OUT/bench_pmc_$name.json 2> $OUT/pmc_$name.err || { tail -5 $OUT/pmc_$name.err; echo "pass failed: $pass"; }
 done
 find $OUT -name "*.csv" | head -50
 du -sh $OUT

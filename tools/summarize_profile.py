@@ -6,6 +6,7 @@
     profiles/traffic.json[workload]  HBM bytes per launch (FETCH_SIZE ×2 per the gfx950 correction, + WRITE_SIZE)
 
 usage: tools/summarize_profile.py <tag> <workload> "<kernel substring>;<kernel substring>"
+(the profile key — workload@WxHxspp — and the arithmetic policy are read from the bench line the profile was taken with)
 
 The roofline (DESIGN.md §5 "Roofline"): the trace kernels are bound by VALU ISSUE, not by HBM.  A gfx950 SIMD
 is 32 lanes wide: a full-rate wave64 instruction occupies it for 2 cycles, a half-rate one for 4, a
@@ -35,7 +36,19 @@ SIMDS = 1024          # 256 CUs × 4
 PEAK_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
-lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
+ARITH = {"ieee": 0, "rocm-opencl-nocontract": 1, "rocm-opencl": 2}
+bench_line = {}
+_bl = os.path.join(src, "bench_trace.json")
+if os.path.isfile(_bl) and os.path.getsize(_bl):
+    try:
+        bench_line = json.loads([l for l in open(_bl).read().strip().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        bench_line = {}
+arith = bench_line.get("arith", "rocm-opencl")
+key = bench_line.get("config", {}).get("profile_key", workload)
+NS = "pt_a%d::" % ARITH[arith]
+
+lines = ["# rocprofv3 summary `%s` (workload %s, arithmetic policy %s)" % (tag, key, arith), ""]
 
 
 def newest(pattern, window=1500.0):
@@ -67,7 +80,7 @@ if stats:
 bench = os.path.join(src, "bench_trace.json")
 if os.path.isfile(bench) and os.path.getsize(bench):
     try:
-        b = json.loads(open(bench).read().strip().splitlines()[-1])
+        b = bench_line
         lines += ["bench.py under the tracer: value %.1f %s, kernel_ms (HIP events, whole trace call) %.4f" %
                   (b["value"], b["unit"], b["roofline"]["kernel_ms"]), ""]
     except Exception:
@@ -78,7 +91,7 @@ for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = short(r["Kernel_Name"])
         for k in KERNELS:
-            if name.startswith(k.rstrip(">")) and "<true" not in name[:len("pt_samples_q<true")]:
+            if name.startswith(NS + k.rstrip(">")) and "<true" not in name[:len(NS + "pt_samples_q<true")]:
                 per_kernel.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 per_kernel = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per_kernel.items()}
 
@@ -91,7 +104,7 @@ if per_kernel:
         lines.append("| %s | " % c + " | ".join("%.5g" % per_kernel[n][c] if c in per_kernel[n] else "" for n in names) + " |")
     lines.append("")
 
-isa = {k["demangled"]: k for k in isa_stats.kernels(isa_stats.device_asm()).values()}
+isa = {k["demangled"]: k for k in isa_stats.kernels(isa_stats.device_asm(arith=ARITH[arith])).values()}
 mix_out = {}
 for name, m in sorted(per_kernel.items()):
     if "SQ_INSTS_VALU" not in m or "GRBM_GUI_ACTIVE" not in m:
@@ -160,13 +173,13 @@ if mix_out:
     allmix = json.load(open(path)) if os.path.isfile(path) else {}
     import __graft_entry__ as g
     # the device sources the counts were measured on: bench.py compares (profile_matches_source)
-    allmix[workload] = {"profile": tag, "kernels": mix_out, "source_digest": g.device_source_digest()}
+    allmix[key] = {"profile": tag, "arith": arith, "kernels": mix_out, "source_digest": g.device_source_digest()}
     json.dump(allmix, open(path, "w"), indent=1, sort_keys=True)
     hb = [v["hbm_bytes"] for v in mix_out.values() if v["hbm_bytes"]]
     if hb:
         tpath = os.path.join(dst, "traffic.json")
         t = json.load(open(tpath)) if os.path.isfile(tpath) else {}
-        t[workload] = {"hbm_bytes_per_launch": int(sum(hb)), "profile": tag,
+        t[key] = {"hbm_bytes_per_launch": int(sum(hb)), "profile": tag,
                        "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, summed over the kernels of one trace call"}
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
 
