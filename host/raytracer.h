@@ -31,7 +31,9 @@ class RayTracer {
     void upload();
 
 public:
-    static const char *defaultScenePath() { return "assets/scenes/c2_cornell.scene"; }
+    // the reference's constructor loads this path, relative to the working directory (src/raytracer.cpp:95); the
+    // repository ships its own file of that name (assets/scenes/scene.scene)
+    static const char *defaultScenePath() { return "assets/scenes/scene.scene"; }
     static void throwOnError(bool on) { throw_on_error = on; }
 
     // kernel_path is accepted for source compatibility with

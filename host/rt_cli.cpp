@@ -23,7 +23,8 @@ static void usage() {
 }
 
 int main(int argc, char **argv) {
-    std::string scene_path = RayTracer::defaultScenePath(), out_tga, out_pfm, out_raw, dump_scene;
+    std::string scene_path = "assets/scenes/c2_cornell.scene", out_tga   // (the façade's own default is the reference's path, assets/scenes/scene.scene)
+        , out_pfm, out_raw, dump_scene;
     int w = 1200, h = 800, spp = 16, device = 0, fov = 60;  // the reference's window is 1200x800 (main.cpp:9-12)
     float cam[5] = {0, 0, 0, 0, 0};
     unsigned long long seed = 0xC0FFEE;

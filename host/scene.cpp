@@ -464,7 +464,15 @@ void SceneCreator::loadTextures() {
         tex_layers = 0;
         return;
     }
-    if (texture_paths.empty()) fail("ERROR: TEXTURE COUNT = 0");
+    // The reference exits here with "ERROR: TEXTURE COUNT = 0" whenever a scene has models but no texture path was
+    // collected (src/scene.cpp:147-148) — i.e. for EVERY model whose material is not t_textured (processMesh only
+    // collects paths for that type, :264), although the kernel never fetches a texel for such a model.  BASELINE.json's
+    // configuration 5 is exactly that (an OBJ mesh with a dielectric material), so this is accepted: no layers.
+    if (texture_paths.empty()) {
+        tex_layers = 0;
+        texture_data.clear();
+        return;
+    }
     texture_data.clear();
     tex_layers = 0;
     std::vector<std::string> dirs;

@@ -159,7 +159,10 @@ class DeviceBuffer:
 
 
 class RayTracer:
-    DEFAULT_SCENE = os.path.join(os.path.dirname(_HERE), "assets", "scenes", "c2_cornell.scene")
+    # the reference hard-codes "assets/scenes/scene.scene" relative to the working directory (src/raytracer.cpp:95): that
+    # path is tried as written first, then this repository's own file of that name
+    DEFAULT_SCENE = os.path.join("assets", "scenes", "scene.scene")
+    REPO_DEFAULT_SCENE = os.path.join(os.path.dirname(_HERE), "assets", "scenes", "scene.scene")
 
     def __init__(self, w, h, kernel_path=None, scene=None, device=0, seed=0xC0FFEE):
         """``kernel_path`` is accepted for source compatibility with
@@ -177,7 +180,7 @@ class RayTracer:
         if seed != 0xC0FFEE:
             self.setSeed(seed)
         if scene is None:
-            scene = self.DEFAULT_SCENE
+            scene = self.DEFAULT_SCENE if os.path.isfile(self.DEFAULT_SCENE) else self.REPO_DEFAULT_SCENE
         if isinstance(scene, str):
             path = scene
             scene = SceneCreator()

@@ -96,12 +96,9 @@ def _camera(width, height, pos, yaw, pitch=0.0, fov=60):
 def c1(width=256, height=256, spp=1):
     """C1: single sphere + plane, 256×256, 1 spp (plumbing)."""
     s = SceneCreator()
-    s.addMaterial(_abi.T_DIFFUSE, (1, 0, 0), 1)  # 0 red diffuse
-    s.addMaterial(_abi.T_LIGHT, (1, 1, 1), 0)    # 1 light
-    s.addSphere((0, 0, 3), 1, 0)
-    s.addPlane((0, 5, 0), (0, 1, 0), 1)
+    s.loadScene(os.path.join(_ASSETS, "scenes", "c1_sphere.scene"))
     return Workload("c1", s, _camera(width, height, (0, 0, 0), 0.0), width, height, spp,
-                    "1 sphere + 1 plane")
+                    "1 sphere + 1 plane (assets/scenes/c1_sphere.scene)")
 
 
 def c2(width=1920, height=1080, spp=64):
@@ -160,60 +157,90 @@ def c4(width=1920, height=1080, spp=64, n_spheres=100000, seed=SEED):
                     "%d random spheres + plane" % n_spheres)
 
 
-def uv_sphere(segments=200, rings=126, radius=1.0, centre=(0.0, 0.0, 0.0)):
-    """Closed convex uv-sphere, outward (counter-clockwise) winding so the reference's
-    hitMeshOut assumptions hold (raytracer.cl:284,292): 2·segments·(rings−1) triangles,
-    one vertex per face corner (the layout Assimp would emit)."""
-    th = (np.arange(rings + 1, dtype=np.float64) / rings) * np.pi          # polar
+def uv_sphere_grid(segments=200, rings=126, radius=1.0, centre=(0.0, 0.0, 0.0)):
+    """Closed convex uv-sphere as an indexed mesh: (rings+1)·(segments+1) grid vertices (float64 positions, uv) and
+    2·segments·(rings−1) triangles as index triples into the grid, every face counter-clockwise seen from outside so
+    that the reference's hitMeshOut assumptions hold (raytracer.cl:284,292).  Degenerate triangles at the poles are
+    left out."""
+    th = (np.arange(rings + 1, dtype=np.float64) / rings) * np.pi            # polar
     ph = (np.arange(segments + 1, dtype=np.float64) / segments) * 2 * np.pi  # azimuth
+    ii, jj = np.meshgrid(np.arange(rings + 1), np.arange(segments + 1), indexing="ij")
+    unit = np.stack([np.sin(th[ii]) * np.cos(ph[jj]), np.cos(th[ii]) * np.ones_like(ph[jj]), np.sin(th[ii]) * np.sin(ph[jj])],
+                    axis=-1).reshape(-1, 3)
+    uv = np.stack([ph[jj] / (2 * np.pi), th[ii] / np.pi * np.ones_like(ph[jj])], axis=-1).reshape(-1, 2)
 
-    def P(i, j):
-        one = np.ones(len(j))
-        return np.stack([np.sin(th[i]) * np.cos(ph[j]), np.cos(th[i]) * one, np.sin(th[i]) * np.sin(ph[j])], axis=-1)
+    def vid(i, j):
+        return i * (segments + 1) + j
 
-    def UV(i, j):
-        return np.stack([ph[j] / (2 * np.pi), th[i] / np.pi * np.ones(len(j))], axis=-1)
-
-    tri_p, tri_uv = [], []
+    tris = []
     j = np.arange(segments)
     for i in range(rings):
-        a, b, c, d = (i, j), (i, j + 1), (i + 1, j + 1), (i + 1, j)
-        quads = []
+        a, b, c, d = vid(i, j), vid(i, j + 1), vid(i + 1, j + 1), vid(i + 1, j)
         if i > 0:
-            quads.append((a, c, b))      # upper triangle (degenerate at the north pole → skipped)
+            tris.append(np.stack([a, c, b], axis=1))      # upper triangle (degenerate at the north pole → skipped)
         if i < rings - 1:
-            quads.append((a, d, c))      # lower triangle (degenerate at the south pole → skipped)
-        for t in quads:
-            tri_p.append(np.stack([P(*t[0]), P(*t[1]), P(*t[2])], axis=1))
-            tri_uv.append(np.stack([UV(*t[0]), UV(*t[1]), UV(*t[2])], axis=1))
-    pos = np.concatenate(tri_p).reshape(-1, 3)
-    uv = np.concatenate(tri_uv).reshape(-1, 2)
+            tris.append(np.stack([a, d, c], axis=1))      # lower triangle (degenerate at the south pole → skipped)
+    tri = np.concatenate(tris)
     # make every face counter-clockwise seen from outside (normal·centroid > 0)
-    tri = pos.reshape(-1, 3, 3)
-    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
-    flip = np.einsum("ij,ij->i", nrm, tri.mean(axis=1)) < 0
+    P = unit[tri]
+    nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    flip = np.einsum("ij,ij->i", nrm, P.mean(axis=1)) < 0
     tri[flip] = tri[flip][:, [0, 2, 1]]
-    uvt = uv.reshape(-1, 3, 2)
-    uvt[flip] = uvt[flip][:, [0, 2, 1]]
-    pos = (tri.reshape(-1, 3) * radius + np.asarray(centre)).astype(f32)
-    return pos, uvt.reshape(-1, 2).astype(f32), np.arange(len(pos), dtype=np.uint32)
+    return unit * radius + np.asarray(centre), uv, tri.astype(np.uint32)
+
+
+def uv_sphere(segments=200, rings=126, radius=1.0, centre=(0.0, 0.0, 0.0)):
+    """The same sphere with one vertex per face corner (the layout Assimp emits, src/scene.cpp:234-262):
+    positions, uvs, indices 0..n-1."""
+    pos, uv, tri = uv_sphere_grid(segments, rings, radius, centre)
+    return pos[tri.reshape(-1)].astype(f32), uv[tri.reshape(-1)].astype(f32), np.arange(3 * len(tri), dtype=np.uint32)
+
+
+C5_OBJ = os.path.join(_ASSETS, "models", "c5_sphere.obj")
+
+
+def write_c5_obj(path=C5_OBJ, segments=200, rings=126):
+    """assets/models/c5_sphere.obj (tools/make_c5_obj.py): BASELINE's "50k-triangle OBJ mesh" as a Wavefront file —
+    the grid vertices once, faces as v/vt index triples.  Coordinates are written with 9 significant digits (every
+    binary32 value survives the trip through text); the v coordinate of `vt` is stored flipped, the way an OBJ
+    exporter writes it and aiProcess_FlipUVs (src/scene.cpp:195) undoes it."""
+    pos, uv, tri = uv_sphere_grid(segments, rings, radius=2.5, centre=(0.0, 2.0, 0.0))
+    p32, uv32 = pos.astype(f32), uv.astype(f32)
+    with open(path, "w") as fh:
+        fh.write("# c5_sphere: closed uv-sphere, %d segments x %d rings, %d triangles, radius 2.5 about (0, 2, 0);\n"
+                 "# counter-clockwise seen from outside.  Written by tools/make_c5_obj.py — do not edit.\no c5_sphere\n" %
+                 (segments, rings, len(tri)))
+        for x, y, z in p32:
+            fh.write("v %.9g %.9g %.9g\n" % (x, y, z))
+        for u, v in uv32:
+            fh.write("vt %.9g %.9g\n" % (u, f32(1.0) - v))
+        for a, b, c in tri + 1:
+            fh.write("f %d/%d %d/%d %d/%d\n" % (a, a, b, b, c, c))
+    return path
 
 
 def c5(width=3840, height=2160, spp=512, segments=200, rings=126):
-    """C5: 50 000-triangle dielectric mesh on a diffuse plane under a light sphere."""
+    """C5: 50 000-triangle dielectric OBJ mesh on a diffuse plane under a light sphere (assets/scenes/c5_mesh.scene →
+    assets/models/c5_sphere.obj through the OBJ reader).  Other segment / ring counts (tests, rehearsals) build the
+    same scene from the generator directly."""
     s = SceneCreator()
-    s.addMaterial(_abi.T_DIELECTRIC, (1, 1, 1), 1.3)  # 0
-    s.addMaterial(_abi.T_DIFFUSE, (0.8, 0.8, 0.8), 1)  # 1
-    s.addMaterial(_abi.T_LIGHT, (1, 1, 1), 0)          # 2
-    s.addMaterial(_abi.T_DIFFUSE, (0.9, 0.3, 0.2), 1)  # 3
-    pos, uv, idx = uv_sphere(segments, rings, radius=2.5, centre=(0.0, 2.0, 0.0))
-    s.addMesh(pos, uv, idx)
-    s.addModel(1, 0)
-    s.addSphere((1, -200, 0), 100, 2)
-    s.addSphere((-4.5, 3.5, 1.0), 1.5, 3)
-    s.addPlane((0, 5, 0), (0, 1, 0), 1)
+    if (segments, rings) == (200, 126):
+        if not os.path.isfile(C5_OBJ):
+            write_c5_obj()
+        s.loadScene(os.path.join(_ASSETS, "scenes", "c5_mesh.scene"), base_dir=_ASSETS)
+    else:
+        s.addMaterial(_abi.T_DIELECTRIC, (1, 1, 1), 1.3)  # 0
+        s.addMaterial(_abi.T_DIFFUSE, (0.8, 0.8, 0.8), 1)  # 1
+        s.addMaterial(_abi.T_LIGHT, (1, 1, 1), 0)          # 2
+        s.addMaterial(_abi.T_DIFFUSE, (0.9, 0.3, 0.2), 1)  # 3
+        pos, uv, idx = uv_sphere(segments, rings, radius=2.5, centre=(0.0, 2.0, 0.0))
+        s.addMesh(pos, uv, idx)
+        s.addModel(1, 0)
+        s.addSphere((1, -200, 0), 100, 2)
+        s.addSphere((-4.5, 3.5, 1.0), 1.5, 3)
+        s.addPlane((0, 5, 0), (0, 1, 0), 1)
     return Workload("c5", s, _camera(width, height, (-7, 0, -7), 45.0, 8.0), width, height, spp,
-                    "%d-triangle dielectric uv-sphere + 2 spheres + plane" % (len(idx) // 3))
+                    "%d-triangle dielectric uv-sphere (OBJ) + 2 spheres + plane" % (len(s.indices) // 3))
 
 
 def shipped_like(width=1200, height=800, spp=16):

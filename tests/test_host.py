@@ -194,3 +194,41 @@ def test_workload_shapes():
     c5 = w.get("c5")
     assert int(c5.scene.meshes["face_count"][0]) == 50000 and (c5.width, c5.height, c5.spp) == (3840, 2160, 512)
     assert [w.get(n).spp for n in ("c1", "c2", "c3", "c4")] == [1, 64, 256, 64]
+
+
+def test_default_scene_is_the_references_path_and_the_repositorys_own_file():
+    """RayTracer(w, h, kernel_path) loads "assets/scenes/scene.scene" like the reference (src/raytracer.cpp:95) — the
+    repository ships its own file of that name (spheres, plane, lens, two textured boxes, ten materials)."""
+    assert rt.RayTracer.DEFAULT_SCENE == os.path.join("assets", "scenes", "scene.scene")
+    assert 'return "assets/scenes/scene.scene"' in open(os.path.join(ROOT, "host", "raytracer.h")).read()
+    s = rt.SceneCreator()
+    s.loadScene(rt.RayTracer.REPO_DEFAULT_SCENE)
+    s.loadTextures()
+    assert (len(s.materials), len(s.spheres), len(s.planes), len(s.lenses), len(s.models)) == (10, 10, 1, 1, 2)
+    assert s.textures.shape[0] == 2 and list(s.meshes["face_count"]) == [12, 12]
+    ref = "/root/reference/assets/scenes/scene.scene"
+    if os.path.isfile(ref):     # authored here, not the reference's file
+        assert open(ref).read() != open(rt.RayTracer.REPO_DEFAULT_SCENE).read()
+
+
+def test_c1_and_c5_come_from_scene_and_obj_files():
+    """BASELINE.json: config 1 is an "assets/scenes single-sphere + plane", config 5 a "50k-triangle OBJ mesh": both
+    workloads are read from files (assets/scenes/c1_sphere.scene; assets/scenes/c5_mesh.scene → assets/models/
+    c5_sphere.obj through the OBJ reader, src/scene.cpp:192-295) and equal the generated arrays: positions and
+    indices bit for bit; the uv array to its last bit but one (FlipUVs computes 1 - v in binary32, which cannot
+    reproduce every v < 0.5 — C5's material is dielectric, no texel is ever fetched)."""
+    a = rt._abi
+    c1 = rt.workloads.get("c1").scene
+    assert len(c1.spheres) == 1 and len(c1.planes) == 1 and list(c1.materials["type"]) == [a.T_DIFFUSE, a.T_LIGHT]
+    assert tuple(c1.spheres["pos"][0][:3]) == (0.0, 0.0, 3.0) and c1.spheres["r"][0] == 1.0
+    c5 = rt.workloads.get("c5").scene
+    pos, uv, idx = rt.workloads.uv_sphere(200, 126, radius=2.5, centre=(0.0, 2.0, 0.0))
+    assert len(idx) == 150000 and list(c5.meshes["face_count"]) == [50000]
+    assert np.array_equal(c5.vertices[:, :3].view(np.uint32), pos.view(np.uint32))
+    assert np.array_equal(c5.indices, idx)
+    assert np.abs(c5.texture_uv - uv).max() <= 2.0 ** -25
+    # the committed OBJ is what the generator writes
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        rt.workloads.write_c5_obj(os.path.join(d, "x.obj"))
+        assert open(os.path.join(d, "x.obj")).read() == open(rt.workloads.C5_OBJ).read()

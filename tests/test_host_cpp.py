@@ -41,7 +41,8 @@ def dump(scene, cam, size, tmp_path):
     return counts, camblock, parts, tex
 
 
-@pytest.mark.parametrize("scene", ["c2_cornell.scene", "c3_cube.scene", "all_kinds.scene"])
+@pytest.mark.parametrize("scene", ["c2_cornell.scene", "c3_cube.scene", "all_kinds.scene", "scene.scene", "c1_sphere.scene",
+                                   "c5_mesh.scene"])
 def test_cpp_scene_arrays_match_python(built, scene, tmp_path):
     cam = (-8.0, -1.0, -8.0, 45.0, 0.0)
     counts, camblock, parts, tex = dump(scene, cam, (1200, 800), tmp_path)
