@@ -731,6 +731,40 @@ PT_DEV V3 texture_rgb(const DeviceScene &sc, float s, float t, uint32_t tex_id) 
 // renormalise).
 // set_origin = false: the caller has already moved the ray's origin to the hit point (the queue kernels do so
 // right after the hit search, so that the hit point is not carried in registers of its own).
+// The sample-independent terms of a glass interaction (:371-381, :409-424): facing normal, index ratio, cosine of the
+// incident angle (made negative), Schlick's r0 for that side.  One definition, used by scatter() and by the shared
+// decision tree of pt_prefix (which needs the reflect probability and the discriminant without taking a branch).
+struct GlassTerms {
+    V3 n;
+    float ratio, cai, r0;
+};
+PT_DEV GlassTerms glass_terms(const Ctx &c, V3 d, V3 hn, uint32_t mat, float extra) {
+    // 1/extra and Schlick's r0² per material: from the workgroup's LDS table when there is one
+    float inv_extra, r0_extra, r0_inv;
+    if (c.lmat) {
+        float4 x = lds_ld(c.lmat, 2 * mat + 1);
+        inv_extra = x.y; r0_extra = x.z; r0_inv = x.w;
+    } else {
+        inv_extra = 1.0f / extra;
+        r0_extra = schlick_r0(extra);
+        r0_inv = schlick_r0(inv_extra);
+    }
+    GlassTerms g;
+    g.cai = dot(d, hn);  // cos of the incident angle
+    if (g.cai > 0) {
+        g.n = neg(hn);
+        g.ratio = extra;
+        g.r0 = r0_extra;
+        g.cai = -g.cai;
+    } else {
+        g.n = hn;
+        g.ratio = inv_extra;
+        g.r0 = r0_inv;
+    }
+    return g;
+}
+PT_DEV float glass_disc(const GlassTerms &g) { return nmad(g.ratio * g.ratio, nmad(g.cai, g.cai, 1.0f), 1.0f); }   // 1 - ratio * ratio * (1 - cai * cai)   (:381,:424)
+
 template <bool COUNT>
 PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float extra, V3 col, const Rnd &rnd,
                     bool set_origin = true) {
@@ -745,36 +779,16 @@ PT_DEV void scatter(const Ctx &c, Ray &r, V3 &out, const Hit &h, int type, float
         v = nmad(h.n, k, r.d);   // dir - 2 dot(dir, n) * n
         out = out * extra;  // :366 — only for t_reflective
     } else if (type == RT_REFRACTIVE || type == RT_DIELECTRIC) {
-        V3 n;
-        float ratio, r0;
-        // 1/extra and Schlick's r0² per material: from the workgroup's LDS table when there is one
-        float inv_extra, r0_extra, r0_inv;
-        if (c.lmat) {
-            float4 x = lds_ld(c.lmat, 2 * h.mat + 1);
-            inv_extra = x.y; r0_extra = x.z; r0_inv = x.w;
-        } else {
-            inv_extra = 1.0f / extra;
-            r0_extra = schlick_r0(extra);
-            r0_inv = schlick_r0(inv_extra);
-        }
-        float cai = dot(r.d, h.n);  // cos of the incident angle
-        if (cai > 0) {
-            n = neg(h.n);
-            ratio = extra;
-            r0 = r0_extra;
-            cai = -cai;
-        } else {
-            n = h.n;
-            ratio = inv_extra;
-            r0 = r0_inv;
-        }
+        const GlassTerms g = glass_terms(c, r.d, h.n, h.mat, extra);
+        const V3 n = g.n;
+        const float ratio = g.ratio, cai = g.cai;
         bool want = true;
         if (type == RT_DIELECTRIC) {
             if (COUNT) c.cn->c[CN_N_DIELECTRIC]++;
-            float prob = schlick(-cai, r0);
+            float prob = schlick(-cai, g.r0);
             want = prob < rnd.u;
         }
-        float disc = nmad(ratio * ratio, nmad(cai, cai, 1.0f), 1.0f);   // 1 - ratio * ratio * (1 - cai * cai)   (:381,:424)
+        float disc = glass_disc(g);
         if (want && disc > 0.0f) {
             // ratio * dir - n * (ratio * cai + sqrt(disc))   (:385,:428): the LEFT product is the one clang contracts
             V3 nk = n * mad(ratio, cai, sqrt1(disc));
@@ -834,12 +848,18 @@ PT_DEV Ray primary_ray(const float *cam, uint32_t x, uint32_t y, int w, int h) {
 }
 
 
+// trace_branch: the deterministic stretch of a path from bounce i0 on (ray r, path colour out) up to its next random
+// event — the record of that vertex (REC_VERTEX: a diffuse / textured / dielectric surface) or the path's final
+// colour (REC_FINAL: sky, a light, or DEPTH bounces).  trace_prefix is the stretch that starts at the camera.
+// max_stretch: after that many deterministic bounces (mirror / glass chains) the stretch is cut short at the next hit,
+// which is returned as a vertex of whatever material it has — the samples take it from there (their kernels'
+// interaction step handles every material).  pt_prefix follows its stretch to the end; the tree builder, whose
+// launches last as long as their longest stretch, does not.
 template <bool COUNT, bool ACCEL>
-PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
+PT_DEV PixelRec trace_branch(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t max_stretch = RT_DEPTH) {
     PixelRec rec;
-    V3 out = mk(1.0f, 1.0f, 1.0f);
     rec.p_kind = rec.n_extra = rec.d = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t i = 0; i < RT_DEPTH; i++) {
+    for (uint32_t i = i0; i < RT_DEPTH; i++) {
         Hit h;
         if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
             out = mk(0.0f, 0.0f, 0.0f);
@@ -854,7 +874,7 @@ PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
             out = vmin(out, col);
             break;
         }
-        if (type == RT_DIFFUSE || type == RT_TEXTURED || type == RT_DIELECTRIC) {
+        if (type == RT_DIFFUSE || type == RT_TEXTURED || type == RT_DIELECTRIC || i - i0 >= max_stretch) {
             if (type == RT_TEXTURED) {
                 if (COUNT) c.cn->c[CN_N_TEXFETCH]++;
                 col = texture_rgb(c.sc, h.u, h.v, h.tex);
@@ -876,10 +896,21 @@ PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
     rec.out = make_float4(out.x, out.y, out.z, 0.0f);
     return rec;
 }
+template <bool COUNT, bool ACCEL>
+PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
+    return trace_branch<COUNT, ACCEL>(c, r, mk(1.0f, 1.0f, 1.0f), 0u);
+}
 
 // radiance of one sample continuing from its pixel's record
+PT_DEV const float4 *tree_leaf(const PixelTree *tree, const float *__restrict__ table, uint32_t bu);
 template <bool COUNT, bool ACCEL>
-PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, uint32_t gx, uint32_t gy) {
+PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec0, uint32_t sample, uint32_t gx, uint32_t gy,
+                            const PixelTree *trees = nullptr) {
+    PixelRec rec = rec0;
+    if ((__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
+        const float4 *lf = tree_leaf(trees + __float_as_uint(rec.col.w), c.sc.table, rnd_base_u(sample, gx, gy));
+        rec.p_kind = lf[0]; rec.n_extra = lf[1]; rec.d = lf[2]; rec.out = lf[3]; rec.col = lf[4];
+    }
     uint32_t bits = __float_as_uint(rec.p_kind.w);
     if ((bits & 0xFFu) == REC_FINAL) return xyz(rec.out);
     uint32_t depth = (bits >> 8) & 0xFFu;
@@ -897,6 +928,89 @@ PT_DEV V3 radiance_from_rec(const Ctx &c, const PixelRec &rec, uint32_t sample, 
     Rnd rnd = fetch_rnd(c.sc.table, r.d, depth + sample, gx, gy);
     scatter<COUNT>(c, r, out, h, type, rec.n_extra.w, xyz(rec.col), rnd);
     return trace_from<COUNT, ACCEL>(c, r, out, depth + 1, sample, gx, gy);
+}
+
+// ---- shared decision tree (pt_types.hpp PixelTree) ------------------------------------------------------------------
+#ifndef PT_TREE_STRETCH
+#define PT_TREE_STRETCH 3u   // deterministic bounces a continuation is followed for before the samples take over (see trace_branch)
+#endif
+PT_DEV bool is_glass_vertex(const PixelRec &rec) {
+    const uint32_t bits = __float_as_uint(rec.p_kind.w);
+    return (bits & 0xFFu) == REC_VERTEX && (int)(bits >> 16) == RT_DIELECTRIC;
+}
+// One step of the builder for the glass vertex `rec`: what every sample does there regardless of its random number.
+// A vertex whose refraction is impossible (discriminant <= 0: total internal reflection, `reflect_prob < rand &&
+// discriminant > 0` is false for every rand, :426-433) is no decision — the path simply goes on to its next random
+// event, and so on: on return `rec` is either a glass vertex that IS a decision (true; prob = its reflect probability)
+// or some other record (false).
+template <bool ACCEL>
+PT_DEV bool tree_settle(const Ctx &c, PixelRec &rec, float &prob) {
+    // (at most PT_TREE_STRETCH total reflections in a row are followed here; a glass vertex left unexamined after
+    // that is simply a leaf the samples continue from)
+    for (uint32_t k = 0; k <= PT_TREE_STRETCH && is_glass_vertex(rec); k++) {
+        const GlassTerms g = glass_terms(c, xyz(rec.d), xyz(rec.n_extra), __float_as_uint(rec.d.w), rec.n_extra.w);
+        if (glass_disc(g) > 0.0f) {
+            prob = schlick(-g.cai, g.r0);
+            return true;
+        }
+        Ray r;
+        r.o = xyz(rec.p_kind);
+        r.d = xyz(rec.d);
+        Hit h;
+        h.p = r.o;
+        h.n = xyz(rec.n_extra);
+        h.u = h.v = 0.0f;
+        h.tex = 0;
+        h.mat = __float_as_uint(rec.d.w);
+        Rnd force;
+        force.v = mk(0.0f, 0.0f, 0.0f);
+        force.u = -INFINITY;
+        V3 out = xyz(rec.out);
+        scatter<false>(c, r, out, h, RT_DIELECTRIC, rec.n_extra.w, xyz(rec.col), force);
+        rec = trace_branch<false, ACCEL>(c, r, out, ((__float_as_uint(rec.p_kind.w) >> 8) & 0xFFu) + 1u, PT_TREE_STRETCH);
+    }
+    return false;
+}
+// One continuation of the decision vertex `rec` — which = 0: the refracted ray, 1: the reflected one — up to its next
+// random event, traced with the very scatter() a sample runs: the branch is forced through the comparison
+// `prob < u` itself (u = +inf: refract if any u can; u = -inf: reflect).
+template <bool ACCEL>
+PT_DEV PixelRec tree_branch(const Ctx &c, const PixelRec &rec, uint32_t which) {
+    Ray r;
+    r.o = xyz(rec.p_kind);
+    r.d = xyz(rec.d);
+    Hit h;
+    h.p = r.o;
+    h.n = xyz(rec.n_extra);
+    h.u = h.v = 0.0f;
+    h.tex = 0;
+    h.mat = __float_as_uint(rec.d.w);
+    Rnd force;
+    force.v = mk(0.0f, 0.0f, 0.0f);
+    force.u = which ? -INFINITY : INFINITY;
+    V3 out = xyz(rec.out);
+    scatter<false>(c, r, out, h, RT_DIELECTRIC, rec.n_extra.w, xyz(rec.col), force);
+    return trace_branch<false, ACCEL>(c, r, out, ((__float_as_uint(rec.p_kind.w) >> 8) & 0xFFu) + 1u, PT_TREE_STRETCH);
+}
+
+// The leaf a sample continues from: walk the decisions with the sample's own table entries (random(), :120-125:
+// float 300000 + (hash + s_seed·2683 + gid0·3931 + gid1) mod 100000, s_seed = bounce index + sample; bu = the
+// sample's part of that sum, rnd_base_u).  → pointer to the leaf's five float4.
+PT_DEV const float4 *tree_leaf(const PixelTree *tree, const float *__restrict__ table, uint32_t bu) {
+    uint32_t node = 1u, leaf = 0u;
+#pragma unroll 1
+    for (uint32_t guard = 0; guard < PT_TREE_LEVELS; guard++) {
+        const uint4 d = *reinterpret_cast<const uint4 *>(&tree->dec[node]);
+        const uint32_t iu = (d.x + bu + d.z * 2683u) % RT_RANDOM_BUFFER_SIZE;
+        const float u = table[3 * RT_RANDOM_BUFFER_SIZE + iu];
+        const uint32_t ch = (__uint_as_float(d.y) < u ? d.w : d.w >> 16) & 0xFFFFu;
+        if (ch & 0x8000u) {
+            leaf = ch & 0x7FFFu;
+            break;
+        }
+        node = ch;
+    }
+    return reinterpret_cast<const float4 *>(&tree->leaf[leaf]);
 }
 
 }  // namespace PT_NS

@@ -9,6 +9,8 @@
 // (the contractions of policy 2 are written out as fma calls at the reference's sites; the compiler never contracts)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "pt_device.hpp"
 #include "rt_context.hpp"
 #include "pt_kernels.hpp"
@@ -153,11 +155,14 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     uint32_t x = 0, y = 0;
     bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
     bool is_live = false;
+    uint32_t glass_pos = 0u;
     PixelRec rec;
     rec.p_kind = rec.n_extra = rec.d = rec.out = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (valid) {
         Ray r0 = primary_ray(fp.cam, x, y, fp.w, fp.h);
         rec = trace_prefix<COUNT, ACCEL>(c, r0, x, y);
+    }
+    if (valid) {
         uint32_t g = 1u << fp.group_log2;
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         if (final_px && (fp.count & (g - 1u)) == 0) {
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     // 32 400 waves of a 1080p frame queue on a single address: 0.12 of the kernel's 0.20 ms.  Spreading the list
     // over LIVE_SEGMENTS > 1 independent counters removes the queue too, but costs pt_samples_q 13–26 %: the
     // list's ORDER matters to it — see LIVE_SEGMENTS.)  Order within the list is irrelevant to the result.
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t s_wave_n[4], s_base;
     unsigned long long m = __ballot(is_live);
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (lane == 0) s_wave_n[wv] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -193,8 +198,110 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
                        lanes_below(m);
         live[pos] = slot;
         recs[pos] = rec;
+        glass_pos = pos;
+    }
+    // Pixels whose first random event is a dielectric surface are listed for pt_tree_pass (one atomic per wave): their
+    // two continuations through the glass are traced once per pixel there instead of once per sample.
+    {
+        const bool glass = !COUNT && is_live && fp.tree_cap != 0u && is_glass_vertex(rec);
+        const unsigned long long gm = __ballot(glass);
+        if (gm) {
+            uint32_t base = 0u;
+            const int leader = __builtin_ctzll(gm);
+            if ((int)lane == leader) base = atomicAdd(fp.tree_count, (uint32_t)__popcll(gm));
+            base = (uint32_t)__shfl((int)base, leader);
+            const uint32_t gi = base + lanes_below(gm);
+            if (glass && gi < fp.tree_cap) {
+                fp.glass[gi] = glass_pos;
+                fp.trees[gi].dec[0].hsh = 0u;   // the tree's leaf counter
+            }
+        }
     }
     flush_counters<COUNT>(cn, counters, fp.count);  // the prefix stands for `count` samples' worth of work
+}
+
+// Fused path, stage 1b: the shared decision trees (pt_types.hpp PixelTree) of the pixels pt_prefix listed, one LEVEL per
+// launch.  Two work-items per waiting glass vertex — one per continuation (refracted / reflected ray) — so that every
+// work-item traces ONE stretch of path (grid-stride: the work's length is only known on the device).  Level 0 takes
+// the listed pixels' own records (the root, heap node 1) and rewrites them (REC_TREE + tree index; or the one record
+// every sample continues from, when the glass reflects totally); a continuation that ends at another glass vertex
+// waits in `out` for the next level, below the last level it becomes a leaf the samples continue from on their own.
+template <bool ACCEL>
+__global__ __launch_bounds__(256) void pt_tree_pass(DeviceScene sc, FrameParams fp, PixelRec *__restrict__ recs, uint32_t level,
+                                                   const TreeWork *__restrict__ in, const uint32_t *__restrict__ in_count,
+                                                   TreeWork *__restrict__ out, uint32_t *__restrict__ out_count, uint32_t q_cap) {
+    __shared__ float4 s_mat[PT_LDS_STATIC_FLOAT4];
+    Ctx c{sc, stage_materials(sc, s_mat), nullptr};
+    c.lwin = staged_winners(sc, s_mat);
+    c.lpln = staged_planes(sc, s_mat);
+    const uint32_t n = level == 0u ? min(*fp.tree_count, fp.tree_cap) : min(*in_count, q_cap);
+    const uint32_t lane = threadIdx.x & 63u;
+    // (wave-uniform loop: the appends to the next level's queue are one atomic per WAVE — one per work-item made a
+    // hundred thousand atomics queue on a single address, 0.2 ms of a 1.9 ms frame)
+    for (uint32_t t0 = blockIdx.x * 256u + (threadIdx.x & ~63u); t0 < 2u * n; t0 += gridDim.x * 256u) {
+        const uint32_t t = t0 + lane;
+        const bool live = t < 2u * n;
+        const uint32_t item = live ? t >> 1 : 0u, which = t & 1u;
+        uint32_t tree = item, heap = 1u, pos = 0u;
+        PixelRec rec;
+        rec.p_kind = rec.n_extra = rec.d = rec.out = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (REC_FINAL: not a glass vertex)
+        if (live) {
+            if (level == 0u) {
+                pos = fp.glass[item];
+                rec = recs[pos];
+            } else {
+                rec = in[item].rec;
+                tree = in[item].tree;
+                heap = in[item].heap;
+            }
+        }
+        PixelTree *T = fp.trees + tree;
+        float prob = 0.0f;
+        const bool decision = tree_settle<ACCEL>(c, rec, prob) && live;
+        if (live && !decision && which == 0u) {
+            // no decision here after all (total internal reflection led to another kind of vertex): a leaf
+            if (heap == 1u) recs[pos] = rec;   // the pixel needs no tree: the prefix simply went on
+            else {
+                const uint32_t li = atomicAdd(&T->dec[0].hsh, 1u);
+                T->leaf[li] = rec;
+                T->dec[heap >> 1].child[heap & 1u] = (uint16_t)(0x8000u | li);
+            }
+        }
+        if (decision && which == 0u) {
+            T->dec[heap].hsh = dir_hash(xyz(rec.d));
+            T->dec[heap].prob = prob;
+            T->dec[heap].depth = (__float_as_uint(rec.p_kind.w) >> 8) & 0xFFu;
+            if (heap == 1u) {
+                recs[pos].p_kind.w = __uint_as_float((uint32_t)REC_TREE);
+                recs[pos].col.w = __uint_as_float(tree);
+            } else {
+                T->dec[heap >> 1].child[heap & 1u] = (uint16_t)heap;
+            }
+        }
+        PixelRec rb = rec;
+        if (decision) rb = tree_branch<ACCEL>(c, rec, which);
+        const bool wait = decision && is_glass_vertex(rb) && level + 1u < PT_TREE_LEVELS;
+        const unsigned long long wm = __ballot(wait);
+        bool queued = false;
+        if (wm) {
+            uint32_t base = 0u;
+            const int leader = __builtin_ctzll(wm);
+            if ((int)lane == leader) base = atomicAdd(out_count, (uint32_t)__popcll(wm));
+            base = (uint32_t)__shfl((int)base, leader);
+            const uint32_t qi = base + lanes_below(wm);
+            if (wait && qi < q_cap) {
+                out[qi].rec = rb;
+                out[qi].tree = tree;
+                out[qi].heap = 2u * heap + which;
+                queued = true;   // (its parent's child link is written when the vertex is settled, next level)
+            }
+        }
+        if (decision && !queued) {
+            const uint32_t li = atomicAdd(&T->dec[0].hsh, 1u);
+            T->leaf[li] = rb;
+            T->dec[heap].child[which] = (uint16_t)(0x8000u | li);
+        }
+    }
 }
 
 // Fused path, stage 2: one group of g lanes per LIVE pixel; each lane continues
@@ -226,7 +333,7 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
         for (uint32_t s = fp.first + lane; s < fp.first + fp.count; s += g) {
             if (COUNT) cn.c[CN_SAMPLES]++;
-            sum = sum + radiance_from_rec<COUNT, ACCEL>(c, rec, s, x, y);
+            sum = sum + radiance_from_rec<COUNT, ACCEL>(c, rec, s, x, y, fp.trees);
         }
         (void)final_px;
     }
@@ -397,8 +504,13 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                 bv = rnd_base_v(sample, gx, gy);
                 bu = rnd_base_u(sample, gx, gy);
                 uint32_t bits = __float_as_uint(q0.w);
+                if ((bits & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
+                    const float4 *lf = tree_leaf(fp.trees + __float_as_uint(q4.w), sc.table, bu);
+                    q0 = lf[0]; q1 = lf[1]; q2 = lf[2]; q3 = lf[3]; q4 = lf[4];
+                    bits = __float_as_uint(q0.w);
+                }
                 if (COUNT) cn.c[CN_SAMPLES]++;
-                if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
+                if ((bits & 0xFFu) == REC_FINAL) {  // a leaf of a tree, or count is not a multiple of g
                     slot[3 * idx] = q3.x;
                     slot[3 * idx + 1] = q3.y;
                     slot[3 * idx + 2] = q3.z;
@@ -640,7 +752,12 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 bv = rnd_base_v(sample, gx, gy);
                 bu = rnd_base_u(sample, gx, gy);
                 uint32_t bits = __float_as_uint(q0.w);
-                if ((bits & 0xFFu) == REC_FINAL) {  // only when count is not a multiple of g
+                if ((bits & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
+                    const float4 *lf = tree_leaf(fp.trees + __float_as_uint(q4.w), sc.table, bu);
+                    q0 = lf[0]; q1 = lf[1]; q2 = lf[2]; q3 = lf[3]; q4 = lf[4];
+                    bits = __float_as_uint(q0.w);
+                }
+                if ((bits & 0xFFu) == REC_FINAL) {  // a leaf of a tree, or count is not a multiple of g
                     slot[3 * idx] = q3.x;
                     slot[3 * idx + 1] = q3.y;
                     slot[3 * idx + 2] = q3.z;
@@ -1014,12 +1131,15 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         fp.slot_end = b + slots_per_launch < slots ? b + slots_per_launch : slots;
         uint32_t n = fp.slot_end - fp.slot_begin;
         HIP_TRY(ctx, hipMemsetAsync(live_count, 0, (size_t)LIVE_SEGMENTS * LIVE_COUNT_STRIDE * sizeof(uint32_t), ctx->stream));
+        // shared decision trees (RT_OPT_PREFIX_TREE): not in counting builds — the counters price per-sample work
+        fp.trees = ctx->d_trees;
+        fp.glass = ctx->d_glass;
+        fp.tree_count = live_count + LIVE_TREE_COUNTER;
+        fp.tree_cap = (ctx->prefix_tree && !ctx->count_enabled && ctx->d_trees && ctx->d_tree_work) ? (uint32_t)ctx->tree_capacity : 0u;
         // workgroup b of pt_prefix appends to segment b mod LIVE_SEGMENTS: a segment holds at most seg_cap entries
         const uint32_t prefix_blocks = (n + 255) / 256;
         fp.seg_cap = ((prefix_blocks + LIVE_SEGMENTS - 1) / LIVE_SEGMENTS) * 256u;
-        // sample kernels deal their waves (pixel groups) over the segments: unit u → segment u mod LIVE_SEGMENTS
-        auto units_for = [&](uint32_t per_unit) { return LIVE_SEGMENTS * ((fp.seg_cap + per_unit - 1) / per_unit); };
-        dim3 block(256), grid1(prefix_blocks), grid2((unsigned)((((uint64_t)units_for(1u) << glog2) + 255) / 256));
+        dim3 block(256), grid1(prefix_blocks);
         // sample queue: a wave owns ppw live pixels (<= QUEUE_SLOTS samples); worst case all n pixels are live
         uint32_t static_f4 = lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
@@ -1027,13 +1147,42 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         const bool simple_geom = sc.lens_count == 0 && sc.model_count == 0;   // spheres and planes only
         const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
         uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
-        dim3 gridq((units_for(ppw) + PT_Q_BLOCK_WAVES - 1) / PT_Q_BLOCK_WAVES), blockq(64 * PT_Q_BLOCK_WAVES);
+        dim3 blockq(64 * PT_Q_BLOCK_WAVES);
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
         size_t lds_q = static_f4 * sizeof(float4) + PT_Q_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw, count);
 #define PT_CALL_PREFIX(C, A) \
     hipLaunchKernelGGL((pt_prefix<C, A>), grid1, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
+        bool accel_on = scene_has_accel(sc);
+        PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
+        if (fp.tree_cap) {
+            // stage 1b: the decision trees of the glass-first pixels, level by level (grid-stride over device-side lists;
+            // a modest grid: 4096 workgroups that stage the materials and find next to nothing to do cost 0.06 ms each).
+            // These launches are latency-bound — each lasts as long as its longest stretch of path, 30-60 us with a few
+            // thousand waves in flight (PT_TREE_STRETCH bounds it).  Tried and measured slower (profiles/r03_experiments.md):
+            // the glass-first pixels in a list of their own, trees and a second launch of the sample kernel on a side
+            // stream beside the main list's — a queue-kernel wave lives ~0.1 ms whatever the size of its launch.
+            dim3 gridt(std::min<uint32_t>(768u, (2u * fp.tree_cap + 255u) / 256u));
+            const uint32_t q_cap = (uint32_t)ctx->tree_capacity;
+            TreeWork *q[2] = {ctx->d_tree_work, ctx->d_tree_work + ctx->tree_capacity};
+            for (uint32_t level = 0; level < PT_TREE_LEVELS; level++) {
+                const TreeWork *in = level ? q[(level - 1u) & 1u] : nullptr;
+                const uint32_t *in_count = level ? fp.tree_count + level : nullptr;
+                TreeWork *out = q[level & 1u];
+                uint32_t *out_count = fp.tree_count + level + 1u;
+                if (accel_on) hipLaunchKernelGGL(pt_tree_pass<true>, gridt, block, 0, ctx->stream, sc, fp, ctx->d_recs, level, in, in_count, out, out_count, q_cap);
+                else hipLaunchKernelGGL(pt_tree_pass<false>, gridt, block, 0, ctx->stream, sc, fp, ctx->d_recs, level, in, in_count, out, out_count, q_cap);
+            }
+        }
+        HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // (the last slot range's; one range is the normal case)
+        // the sample kernel over a list: (records, slots, its counter, its capacity)
+        auto launch_samples = [&](hipStream_t st, const PixelRec *l_recs, const uint32_t *l_live, const uint32_t *l_count, uint32_t l_cap) {
+            FrameParams fl = fp;
+            fl.seg_cap = l_cap;
+            auto units = [&](uint32_t per_unit) { return LIVE_SEGMENTS * ((l_cap + per_unit - 1) / per_unit); };
+            dim3 gridq((units(ppw) + PT_Q_BLOCK_WAVES - 1) / PT_Q_BLOCK_WAVES);
+            dim3 grid2((unsigned)((((uint64_t)units(1u) << glog2) + 255) / 256));
 #define PT_CALL_QUEUE_W(C, A, G, W) \
-    hipLaunchKernelGGL((pt_samples_q<C, A, G, W>), gridq, blockq, lds_q, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters, ppw)
+    hipLaunchKernelGGL((pt_samples_q<C, A, G, W>), gridq, blockq, lds_q, st, sc, fl, l_recs, l_live, l_count, ctx->d_accum, ctx->d_counters, ppw)
 #define PT_CALL_QUEUE(C, A)                                                                       \
     do {                                                                                          \
         if (!(A)) { if (simple_geom) PT_CALL_QUEUE_W(C, false, 0, PT_Q_WAVES); else PT_CALL_QUEUE_W(C, false, 1, PT_Q_WAVES); } \
@@ -1041,35 +1190,34 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         else PT_CALL_QUEUE_W(C, true, 2, PT_Q_WAVES_ACCEL);                                       \
     } while (0)
 #define PT_CALL_FIXED(C, A) \
-    hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count, ctx->d_accum, ctx->d_counters)
-        bool accel_on = scene_has_accel(sc);
-        PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_PREFIX);
-        HIP_TRY(ctx, hipEventRecord(evp[2], ctx->stream));  // (the last slot range's; one range is the normal case)
-        if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
-            // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
-            uint32_t ppw_w = queue_pixels_per_wave(count, ctx->walk_jobs.n == 1 ? PT_W_WAVES : PT_W_WAVES_MULTI, static_f4, PT_W_BLOCK_WAVES);
-            size_t lds_w = static_f4 * sizeof(float4) + PT_W_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw_w, count);
-            dim3 gridw((units_for(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
-            if (ctx->walk_jobs.n == 1)
-                hipLaunchKernelGGL(pt_samples_w<false>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
-                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u
+    hipLaunchKernelGGL((pt_samples<C, A>), grid2, block, 0, st, sc, fl, l_recs, l_live, l_count, ctx->d_accum, ctx->d_counters)
+            if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
+                // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
+                uint32_t ppw_w = queue_pixels_per_wave(count, ctx->walk_jobs.n == 1 ? PT_W_WAVES : PT_W_WAVES_MULTI, static_f4, PT_W_BLOCK_WAVES);
+                size_t lds_w = static_f4 * sizeof(float4) + PT_W_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw_w, count);
+                dim3 gridw((units(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
+                if (ctx->walk_jobs.n == 1)
+                    hipLaunchKernelGGL(pt_samples_w<false>, gridw, blockw, lds_w, st, sc, fl, l_recs, l_live, l_count,
+                                       ctx->d_accum, ppw_w, ctx->walk_jobs.p, 1u
 #ifdef PT_WSTAT
-                                   , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
+                                       , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
 #endif
-                                   );
-            else
-                hipLaunchKernelGGL(pt_samples_w<true>, gridw, blockw, lds_w, ctx->stream, sc, fp, ctx->d_recs, ctx->d_live, live_count,
-                                   ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n
+                                       );
+                else
+                    hipLaunchKernelGGL(pt_samples_w<true>, gridw, blockw, lds_w, st, sc, fl, l_recs, l_live, l_count,
+                                       ctx->d_accum, ppw_w, ctx->walk_jobs.p, (uint32_t)ctx->walk_jobs.n
 #ifdef PT_WSTAT
-                                   , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
+                                       , ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 8
 #endif
-                                   );
-        } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
-        else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
-#undef PT_CALL_PREFIX
+                                       );
+            } else if (queue) PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_QUEUE);
+            else PT_DISPATCH(ctx->count_enabled, accel_on, PT_CALL_FIXED);
 #undef PT_CALL_QUEUE
 #undef PT_CALL_QUEUE_W
 #undef PT_CALL_FIXED
+        };
+        launch_samples(ctx->stream, ctx->d_recs, ctx->d_live, live_count, fp.seg_cap);
+#undef PT_CALL_PREFIX
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(evp[1], ctx->stream));

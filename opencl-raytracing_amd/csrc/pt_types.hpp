@@ -97,7 +97,39 @@ struct PixelRec {        // 80 bytes
     float4 out;          // path colour so far (kind 1) or the pixel's radiance for every sample (kind 0)
     float4 col;          // material colour / texel
 };
-enum { REC_FINAL = 0, REC_VERTEX = 1 };
+enum { REC_FINAL = 0, REC_VERTEX = 1, REC_TREE = 2 };
+
+// ---- shared decision tree of a pixel -------------------------------------------------------------------------------
+// A dielectric surface is a random event with only TWO outcomes — refract or reflect (raytracer.cl:407-435): which one a
+// sample takes depends on its own table entry u (reflect_prob < u → refract), but the two continuations are the same
+// two rays for every sample of the pixel.  They are therefore followed ONCE per pixel, each up to its next random event,
+// and the result is kept as a small binary tree (PT_TREE_LEVELS levels of decisions, heap-indexed: node h has the
+// children 2h and 2h + 1): decision nodes hold what a sample needs to choose — the hash of the incoming direction and
+// the bounce index that form its table index, and the reflect probability — leaves are ordinary pixel records (a
+// diffuse / textured vertex, a final colour, or — below the last level — a dielectric vertex the samples continue
+// from on their own).  The sample kernels walk the decisions per sample (one table read each) and start from the
+// chosen leaf: the nearest-hit searches behind the glass are done once per pixel instead of once per sample.  A record
+// of kind REC_TREE names its tree in col.w.  Bits are unchanged: the same operations, not repeated per sample.
+// Built level by level (pt_tree_pass): two work-items per waiting glass vertex, one per continuation.
+#ifndef PT_TREE_LEVELS
+#define PT_TREE_LEVELS 2      // A/B on MI355X, whole fused call (profiles/r03_experiments.md): C2 off 1.927 ms, 1 level ?, 2 levels 1.822, 3 levels 1.867; C5 at 1080p x 512 spp 174.0 / 149.5 / 149.7
+#endif
+#define PT_TREE_DECISIONS ((1 << PT_TREE_LEVELS) - 1)
+#define PT_TREE_LEAVES (1 << PT_TREE_LEVELS)   // a binary tree with 2^L - 1 inner nodes has at most 2^L leaves
+struct TreeDecision {   // 16 bytes
+    uint32_t hsh;       // dir_hash of the direction the ray arrives with (random(), :121); [0]: the tree's leaf counter
+    float prob;         // Schlick's reflect probability (:420); a sample refracts iff prob < u
+    uint32_t depth;     // bounce index i of the vertex (s_seed = i + sample, :471)
+    uint16_t child[2];  // [0]: where a refracting sample goes, [1]: a reflecting one — 0x8000 | leaf, or the decision's heap index
+};
+struct PixelTree {      // 8 x 16 + 8 x 80 = 768 bytes at 3 levels
+    TreeDecision dec[PT_TREE_DECISIONS + 1];   // heap-indexed from 1
+    PixelRec leaf[PT_TREE_LEAVES];
+};
+struct TreeWork {       // a glass vertex waiting to become node `heap` of tree `tree`
+    PixelRec rec;
+    uint32_t tree, heap, _pad[2];
+};
 
 enum RenderMode { MODE_ACCUM = 0, MODE_TRACE = 1, MODE_RETRACE = 2 };
 
@@ -112,6 +144,10 @@ struct FrameParams {
     uint32_t group_log2;            // lanes per pixel = 1 << group_log2 (<= 64)
     uint32_t seg_cap;               // live list: entries per segment (see LIVE_SEGMENTS)
     float inv_count;                // 1 / count, the IEEE quotient computed on the host: a scalar operand of the queue kernels
+    PixelTree *trees;               // shared decision trees of this launch (pt_tree writes, the sample kernels read)
+    uint32_t *glass;                // live-list positions of the pixels whose first random event is a dielectric surface
+    uint32_t *tree_count;           // how many pt_prefix listed (tree i belongs to glass[i])
+    uint32_t tree_cap;              // capacity of `trees` (0: trees off — RT_OPT_PREFIX_TREE, counting builds)
 };
 
 // The live list (pixels that need per-sample work) can be kept in LIVE_SEGMENTS independent segments, workgroup b
@@ -125,6 +161,7 @@ struct FrameParams {
 #define LIVE_SEGMENTS 1u
 #endif
 #define LIVE_COUNT_STRIDE 32u   // counters 128 bytes apart: one L2 line each
+#define LIVE_TREE_COUNTER 16u   // words of the live-count block (zeroed with it): [16] glass-first pixels = trees, [17], [18] the work of levels 1, 2
 
 // Counters are spread over COUNTER_REPLICAS rows (one per workgroup residue) so
 // that two million waves do not serialise on 14 addresses; the host sums the rows.

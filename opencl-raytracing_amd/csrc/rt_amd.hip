@@ -303,9 +303,16 @@ int alloc_frame(rt_context *ctx, int w, int h) {
     ctx->d_image = ctx->d_accum = nullptr;
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_live) (void)hipFree(ctx->d_live);
+    if (ctx->d_trees) (void)hipFree(ctx->d_trees);
+    if (ctx->d_glass) (void)hipFree(ctx->d_glass);
+    if (ctx->d_tree_work) (void)hipFree(ctx->d_tree_work);
+    ctx->d_tree_work = nullptr;
     ctx->d_recs = nullptr;
     ctx->d_live = nullptr;
+    ctx->d_trees = nullptr;
+    ctx->d_glass = nullptr;
     ctx->slot_capacity = 0;
+    ctx->tree_capacity = 0;
     size_t bytes = (size_t)w * h * sizeof(float4);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_image, bytes));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_accum, bytes));
@@ -424,6 +431,7 @@ int rt_create(int device, int width, int height, rt_context **out) {
     if (hipMalloc((void **)&ctx->d_counters, (COUNTER_REPLICAS * COUNTER_STRIDE + 32) * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, (COUNTER_REPLICAS * COUNTER_STRIDE + 32) * sizeof(unsigned long long)) != hipSuccess) { ctx->error = "counter allocation failed"; return bail(RT_EHIP); }
     ctx->d_walk_overflow = reinterpret_cast<uint32_t *>(ctx->d_counters + COUNTER_REPLICAS * COUNTER_STRIDE + 24);
+
     ctx->arith = RT_ARITH_IEEE;
     ctx->ks = kernel_set_a0();
     if ((rc = alloc_frame(ctx, width, height)) != RT_OK) return bail(rc);
@@ -445,6 +453,9 @@ void rt_destroy(rt_context *ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_live) (void)hipFree(ctx->d_live);
+    if (ctx->d_trees) (void)hipFree(ctx->d_trees);
+    if (ctx->d_glass) (void)hipFree(ctx->d_glass);
+    if (ctx->d_tree_work) (void)hipFree(ctx->d_tree_work);
     ctx->sph4.release();
     ctx->faces.release();
     ctx->mesh_face_base.release();
@@ -1240,6 +1251,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
         case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
         case RT_OPT_WALK_SLICES: ctx->walk_slices = value != 0; return RT_OK;
+        case RT_OPT_PREFIX_TREE: ctx->prefix_tree = value != 0; return RT_OK;
         case RT_OPT_ACCEL:
             if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_ACCEL takes 0, 1 or 2");
             ctx->accel = value;

@@ -94,6 +94,11 @@ struct rt_context {
     pt::PixelRec *d_recs = nullptr;      // per owned pixel slot: shared path prefix (fused path)
     uint32_t *d_live = nullptr;      // slots that need per-sample work + [capacity] = their count
     size_t slot_capacity = 0;
+    pt::PixelTree *d_trees = nullptr;   // shared decision trees of dielectric-first pixels (pt_types.hpp), tree_capacity of them
+    uint32_t *d_glass = nullptr;        // live-list positions of those pixels (pt_prefix → pt_tree_pass)
+    pt::TreeWork *d_tree_work = nullptr;  // glass vertices waiting for the next level: two queues of tree_capacity entries
+    size_t tree_capacity = 0;
+    bool prefix_tree = true;            // RT_OPT_PREFIX_TREE
     bool prefix_sharing = true;
     bool sample_queue = true;
     DevBuf<uint2> walk_jobs;         // (mesh, model material) of every model's meshes in hit order; empty unless
@@ -197,6 +202,10 @@ inline FrameParams frame_params(const rt_context *ctx, const float cam[12], uint
     fp.count = count;
     fp.group_log2 = glog2;
     fp.seg_cap = 0;
+    fp.trees = nullptr;
+    fp.glass = nullptr;
+    fp.tree_count = nullptr;
+    fp.tree_cap = 0;
     {
         volatile float c = (float)count;
         volatile float q = 1.0f / c;
@@ -212,13 +221,30 @@ inline int ensure_slots(rt_context *ctx, size_t slots) {
     if (slots <= ctx->slot_capacity) return RT_OK;
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_live) (void)hipFree(ctx->d_live);
+    if (ctx->d_trees) (void)hipFree(ctx->d_trees);
+    if (ctx->d_glass) (void)hipFree(ctx->d_glass);
+    if (ctx->d_tree_work) (void)hipFree(ctx->d_tree_work);
+    ctx->d_tree_work = nullptr;
     ctx->d_recs = nullptr;
     ctx->d_live = nullptr;
+    ctx->d_trees = nullptr;
+    ctx->d_glass = nullptr;
     ctx->slot_capacity = 0;
+    ctx->tree_capacity = 0;
     // segmented live list: LIVE_SEGMENTS segments of whole workgroups' worth of entries, then the segment counters
     size_t entries = slots + (size_t)LIVE_SEGMENTS * 256u;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_recs, entries * sizeof(PixelRec)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_live, (entries + (size_t)LIVE_SEGMENTS * LIVE_COUNT_STRIDE) * sizeof(uint32_t)));
+    // decision trees for a quarter of the slots (a frame with more dielectric-first pixels keeps plain records for the rest)
+    ctx->tree_capacity = slots / 4 + 256;
+    if (hipMalloc((void **)&ctx->d_trees, ctx->tree_capacity * sizeof(PixelTree)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_glass, ctx->tree_capacity * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_tree_work, 2 * ctx->tree_capacity * sizeof(TreeWork)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->d_trees) (void)hipFree(ctx->d_trees);
+        ctx->d_trees = nullptr;       // not fatal: the frame renders without shared trees
+        ctx->tree_capacity = 0;
+    }
     ctx->slot_capacity = slots;
     return RT_OK;
 }

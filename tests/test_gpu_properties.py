@@ -675,7 +675,7 @@ def test_live_list_far_shorter_than_the_grid(spp, oracle, table):
         s = rt.SceneCreator()
         s.addMaterial(rt._abi.T_DIFFUSE, (0.9, 0.5, 0.2), 1)
         s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)
-        s.addSphere((0, -300, 0), 100, 1)               # the light, behind the camera's view
+        s.addSphere((0, 0, -300), 100, 1)               # the light, behind the camera: the small sphere's lit side faces it
         if n_spheres:
             s.addSphere((0.0, 0.0, 100.0), 0.3, 0)      # on the axis: pixel (128, 128) looks straight at it, its neighbours
                                                         # (0.45 units apart at that distance) pass beside it
@@ -695,3 +695,71 @@ def test_live_list_far_shorter_than_the_grid(spp, oracle, table):
             assert ref[128, 128, :3].sum() > 0      # the one live pixel: some of its 64 diffuse bounces reach the light
         assert t.walkOverflow() == 0
         t.close()
+
+
+def _glass_stack_scene():
+    """Nested and adjacent glass: concentric dielectric shells, touching dielectric spheres, a refractive ball and a
+    mirror between them, over a diffuse floor — first-hit pixels whose decision trees run out of their budget of 7
+    decisions / 8 leaves, and glass whose refraction is impossible (total internal reflection)."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 1, 1), 1.5)         # 0
+    s.addMaterial(rt._abi.T_DIELECTRIC, (0.9, 1, 0.95), 1.1)    # 1
+    s.addMaterial(rt._abi.T_DIELECTRIC, (1, 0.9, 0.9), 2.4)     # 2 dense: much total internal reflection
+    s.addMaterial(rt._abi.T_REFRACTIVE, (1, 1, 1), 1.3)         # 3
+    s.addMaterial(rt._abi.T_REFLECTIVE, (1, 1, 1), 0.9)         # 4
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.8, 0.8, 0.8), 0.9)      # 5
+    s.addMaterial(rt._abi.T_LIGHT, (1, 1, 1), 0)                # 6
+    s.addSphere((0, -250, 0), 120, 6)
+    for r, m in ((2.4, 0), (1.9, 1), (1.3, 2), (0.6, 0)):       # concentric shells
+        s.addSphere((0, 2.4, 4), r, m)
+    s.addSphere((4.2, 3.2, 3.5), 1.8, 2)
+    s.addSphere((-4.4, 3.4, 4.5), 1.6, 1)
+    s.addSphere((-2.6, 4.0, 1.2), 1.0, 3)
+    s.addSphere((2.3, 4.1, 0.8), 0.9, 4)
+    s.addPlane((0, 5, 0), (0, 1, 0), 5)
+    return s
+
+
+@pytest.mark.parametrize("case", ["c2", "c5", "glass", "all_kinds"])
+@pytest.mark.parametrize("arith", [0, 2])
+def test_decision_trees_change_no_bit(case, arith, oracle, table):
+    """RT_OPT_PREFIX_TREE: a pixel whose first random event is glass gets its two continuations traced once (pt_tree) and
+    its samples only pick their branch — the accumulators must equal the per-sample tracing bit for bit (same samples,
+    same summation order), at sample counts below, at and above a wave, and against the oracle's per-sample values."""
+    if case == "glass":
+        scene, cam, W, H = _glass_stack_scene(), rt.Camera(60, 16 / 9, (0, 0, -6), 0.0, 4.0).transferData(), 320, 180
+    else:
+        wl = rt.workloads.get(case, **({"width": 320, "height": 180} if case != "c5" else {"width": 320, "height": 180, "segments": 48, "rings": 32}))
+        scene, cam, W, H = wl.scene, wl.camera, wl.width, wl.height
+    t = rt.RayTracer(W, H, scene=scene, seed=cases.SEED)
+    t.setArith(arith)
+    t.resetCounters()
+    for spp, first in ((1, 0), (5, 3), (64, 0), (200, 7)):
+        frames = []
+        for tree in (1, 0):
+            t.setOption(t.OPT_PREFIX_TREE, tree)
+            t.clear()
+            t.renderSamples(cam, first, spp)
+            t.sync()
+            frames.append(t.readLinear().copy())
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (case, spp)
+    # the fixed-lane kernel (sample queue off) and slot ranges (several launches per frame) read the trees too
+    t.setOption(t.OPT_PREFIX_TREE, 1)
+    t.setOption(t.OPT_SAMPLE_QUEUE, 0)
+    t.clear(); t.renderSamples(cam, 0, 64); t.sync()
+    fixed = t.readLinear().copy()
+    t.setOption(t.OPT_SAMPLE_QUEUE, 1)
+    t.setOption(t.OPT_MAX_THREADS_PER_LAUNCH, 1 << 16)
+    t.clear(); t.renderSamples(cam, 0, 64); t.sync()
+    ranges = t.readLinear().copy()
+    t.setOption(t.OPT_MAX_THREADS_PER_LAUNCH, 1 << 30)
+    t.clear(); t.renderSamples(cam, 0, 64); t.sync()
+    whole = t.readLinear().copy()
+    assert np.array_equal(fixed.view(np.uint32), whole.view(np.uint32))
+    assert np.array_equal(ranges.view(np.uint32), whole.view(np.uint32))
+    if arith == 0 and scene.textures is None:    # against the CPU oracle: the fused frame within 1e-4 (64 spp)
+        ref, _ = oracle.render(scene, cam, table, W, H, 2, count=64, threads=16)
+        img = t.renderFrame(cam, 64)
+        err = np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)
+        assert err.max() <= 1e-4, err.max()
+    t.close()

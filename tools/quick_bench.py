@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-time survey over workloads and library variants (GPU box):
-    tools/quick_bench.py [--lib=PATH] [--queue=0|1] c2:64 c3:256 c4:2 c5:2[:W:H]
+    tools/quick_bench.py [--lib=PATH] [--queue=0|1] [--arith=0|1|2] [--tree=0|1] c2:64 c3:256 c4:2 c5:2[:W:H]
 Prints the best of 5 HIP-event times of the fused trace call and a hash of the accumulator (every
 variant of the library must print the same hash for the same spec: results never depend on tuning)."""
 import hashlib
@@ -18,6 +18,13 @@ if args and args[0].startswith("--lib="):
 queue = None
 if args and args[0].startswith("--queue="):
     queue = int(args.pop(0)[8:])
+arith, tree = 2, None
+while args and args[0].startswith(("--arith=", "--tree=")):
+    k, v = args.pop(0).split("=")
+    if k == "--arith":
+        arith = int(v)
+    else:
+        tree = int(v)
 for spec in args:
     parts = spec.split(":")
     name, spp = parts[0], int(parts[1])
@@ -28,6 +35,9 @@ for spec in args:
     t = rt.RayTracer(wl.width, wl.height, scene=wl.scene)
     if queue is not None:
         t.setOption(t.OPT_SAMPLE_QUEUE, queue)
+    t.setArith(arith)
+    if tree is not None:
+        t.setOption(t.OPT_PREFIX_TREE, tree)
     t.clear(); t.renderSamples(wl.camera, 0, spp); t.sync()
     digest = hashlib.sha1(t.readLinear().tobytes()).hexdigest()[:12]
     ms = []
