@@ -571,7 +571,10 @@ int rt_set_scene(rt_context *ctx, const rt_scene_desc *d) {
         if (nodes.size() / 4 >= (1u << 26) || lidx.size() >= (1u << 26)) ctx->have_mesh_bvh = false;
         if (nodes.empty()) nodes.resize(4, make_float4(0, 0, 0, 0));
         if (lfaces.empty()) lfaces.resize(3, make_float4(0, 0, 0, 0));
-        {   // device layout: 48 bytes per node (mesh_node_pack)
+        {   // device layout: 48 bytes per node (mesh_node_pack), wide-cone inner nodes spliced out of the links
+            std::vector<uint8_t> is_root(nodes.size() / 4, 0);
+            for (uint32_t m = 0; m < d->mesh_count; m++) if (roots[m] != PT_MESH_BVH_NONE && roots[m] < is_root.size()) is_root[roots[m]] = 1;
+            mesh_collapse_links(nodes, is_root);
             std::vector<float4> packed(nodes.size() / 4 * 3);
             for (size_t n = 0; n < nodes.size() / 4; n++) mesh_node_pack(&nodes[4 * n], &packed[3 * n]);
             HIP_TRY(ctx, ctx->mbvh_nodes.upload(packed.data(), packed.size()));
@@ -1057,6 +1060,17 @@ int rt_debug_check_accel(const rt_scene_desc *d, uint64_t stats[8], char *err, s
             if (!e.empty()) return bad("mesh bvh: " + e);
             for (uint32_t v : visits) if (v != 1) return bad("mesh bvh: a leaf slot is not visited exactly once");
             st.nodes = w.nodes; st.leaves = w.leaves;
+        }
+        {   // the links the device walks (wide-cone inner nodes spliced out): still every leaf exactly once
+            std::vector<float4> dev = nodes;
+            std::vector<uint8_t> is_root(dev.size() / 4, 0);
+            is_root[root] = 1;
+            mesh_collapse_links(dev, is_root);
+            std::vector<uint32_t> visits(lidx.size(), 0);
+            BvhWalkStats w;
+            e = host_walk_threaded(dev, root, visits, w);
+            if (!e.empty()) return bad("mesh bvh (collapsed links): " + e);
+            for (uint32_t v : visits) if (v != 1) return bad("mesh bvh (collapsed links): a leaf slot is not visited exactly once");
         }
         if (lidx.size() != nf) return bad("mesh bvh: leaf slot count != face count");
         std::vector<uint32_t> seen(nf, 0);
