@@ -232,3 +232,15 @@ def test_c1_and_c5_come_from_scene_and_obj_files():
     with tempfile.TemporaryDirectory() as d:
         rt.workloads.write_c5_obj(os.path.join(d, "x.obj"))
         assert open(os.path.join(d, "x.obj")).read() == open(rt.workloads.C5_OBJ).read()
+
+
+@pytest.mark.skipif(not os.path.isfile("/opt/rocm/lib/llvm/bin/clang"), reason="needs ROCm's clang (OpenCL front end + device libraries)")
+def test_rocm_opencl_policy_compiles_to_the_opencl_builds_float_sequences():
+    """Offline early warning (the bit-for-bit check runs on the GPU, tests/test_gpu_ref950.py): every OpenCL builtin the
+    reference calls, compiled by ROCm's OpenCL tool chain, has the same floating-point opcode multiset as its
+    restatement in csrc/pt_arith.hpp (policy 1) compiled by hipcc with the policy's flags — tools/arith_probe.py."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "arith_probe.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("| ok |") == 11

@@ -91,7 +91,9 @@ for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = short(r["Kernel_Name"])
         for k in KERNELS:
-            if name.startswith(NS + k.rstrip(">")) and "<true" not in name[:len(NS + "pt_samples_q<true")]:
+            counting = name.startswith((NS + "pt_prefix<true", NS + "pt_samples_q<true", NS + "pt_samples<true", NS + "pt_render<0, true",
+                                        NS + "pt_render<1, true", NS + "pt_render<2, true"))   # COUNT builds: bench's untimed counting pass
+            if name.startswith(NS + k.rstrip(">")) and not counting:
                 per_kernel.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 per_kernel = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per_kernel.items()}
 
