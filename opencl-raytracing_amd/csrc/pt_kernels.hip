@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void pt_samples(DeviceScene sc, FrameParams fp
 #endif
 // dynamic LDS of pt_samples_q, per workgroup: materials, then per wave {records, coordinates, slots}
 __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wave, uint32_t count) {
-    uint32_t b = pixels_per_wave * 5u * 16u + pixels_per_wave * 2u * 4u + pixels_per_wave * count * 3u * 4u;
+    uint32_t b = pixels_per_wave * 5u * 16u + pixels_per_wave * 4u * 4u + pixels_per_wave * count * 3u * 4u;
     return (b + 15u) & ~15u;
 }
 #ifndef PT_UNIFORM_WAVE
@@ -394,7 +394,7 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
         // therefore rounded DOWN to a multiple of PT_LDS_GRANULE)
         uint32_t budget = 163840u / workgroups / PT_LDS_GRANULE * PT_LDS_GRANULE;
         uint32_t per_wave = (budget - static_float4 * (uint32_t)sizeof(float4)) / block_waves - 15u;
-        uint32_t p = per_wave / (5u * 16u + 2u * 4u + count * 3u * 4u);
+        uint32_t p = per_wave / (5u * 16u + 4u * 4u + count * 3u * 4u);
         if (p * count > QUEUE_SLOTS) p = QUEUE_SLOTS / count;
         return p > QUEUE_MAX_PIXELS ? (uint32_t)QUEUE_MAX_PIXELS : p;
     };
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
-    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
+    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 4u);
     uint32_t pix0 = 0;
     const uint32_t npix = live_take(fp, live_count, blockIdx.x * (uint32_t)PT_Q_BLOCK_WAVES + wave, pixels_per_wave, pix0);
     const uint32_t count = fp.count, total = npix * count;
@@ -458,13 +458,18 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
     if (lane < npix) {
         uint32_t x = 0, y = 0;
         (void)slot_to_pixel(fp, live[pix0 + lane], x, y);
-        s_xy[2 * lane] = x;
-        s_xy[2 * lane + 1] = y;
+        // (x, y, and the pixel's part of the two table index sums: rnd_base_v = (sample·2683 + x·3931 + y·2504)·3 and
+        // rnd_base_u = sample·2683 + x·3931 + y are linear in uint32 arithmetic, so a refill needs two multiplies, not five)
+        s_xy[4 * lane] = x;
+        s_xy[4 * lane + 1] = y;
+        s_xy[4 * lane + 2] = rnd_base_v(0u, x, y);
+        s_xy[4 * lane + 3] = rnd_base_u(0u, x, y);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const float inv_count = fp.inv_count;
+    const uint32_t count_log2 = (count & (count - 1u)) == 0u ? (uint32_t)__builtin_ctz(count) : 0xFFu;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     // Per-lane state carried from one iteration to the next, kept small (the kernel sits on its VGPR budget):
@@ -496,13 +501,13 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                 // pixel of this queue entry: p = idx / count, exactly, without an integer divide:
                 // (idx + 0.5)/count lies >= 0.5/count away from every integer, far more than the rounding
                 // of the float product (idx < 8192, count <= 512)
-                uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);
+                // (a power-of-two count — wave-uniform — needs a shift; otherwise one float multiply:)
+                uint32_t p = count_log2 != 0xFFu ? idx >> count_log2 : (uint32_t)(((float)idx + 0.5f) * inv_count);
                 const uint32_t sample = fp.first + (idx - p * count);
                 float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
                        q4 = rec[5 * p + 4];
-                const uint32_t gx = xy[2 * p], gy = xy[2 * p + 1];
-                bv = rnd_base_v(sample, gx, gy);
-                bu = rnd_base_u(sample, gx, gy);
+                bv = sample * 8049u + xy[4 * p + 2];   // = rnd_base_v(sample, x, y)
+                bu = sample * 2683u + xy[4 * p + 3];   // = rnd_base_u(sample, x, y)
                 uint32_t bits = __float_as_uint(q0.w);
                 if ((bits & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
                     const float4 *lf = tree_leaf(fp.trees + __float_as_uint(q4.w), sc.table, bu);
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                 sum = sum + mk(sl[0], sl[1], sl[2]);
             }
         sum = group_sum(sum, g);
-        if (p < npix && l == 0) accumulate(accum, (size_t)xy[2 * p + 1] * fp.w + xy[2 * p], sum, count);
+        if (p < npix && l == 0) accumulate(accum, (size_t)xy[4 * p + 1] * fp.w + xy[4 * p], sum, count);
     }
     flush_counters<COUNT>(cn, counters, 1);
 }
@@ -651,8 +656,13 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 #ifndef PT_WALK_STEPS
 #define PT_WALK_STEPS 24u  // A/B: 8 → 122.9 ms, 16 → 118.3, 24 → 116.5, 48 → 118.4
 #endif
+#ifndef PT_W_BATCH
+#define PT_W_BATCH 1u   // lanes that must be waiting for a cheap step before the cheap steps run (pt_samples_w).  A/B on C5 at 1080p x 64 spp:
+                        // 1 → 20.87 ms, 8 → 21.14, 16 → 21.41, 24 → 21.79, 32 → 22.42 (16 with slices of 12 / 8 nodes: 20.79 / 21.01):
+                        // waiting lanes cost more than sparsely filled cheap steps — batching stays off
+#endif
 #ifndef PT_W_WAVES
-#define PT_W_WAVES 5  // A/B on C5 at 16 spp: 4 → 116.5 ms, 5 → 110.2, 6 → 116.1
+#define PT_W_WAVES 6  // A/B on C5 at 16 spp (round 2, 92 VGPRs): 4 → 116.5 ms, 5 → 110.2, 6 → 116.1 (spills); round 3 (the loop reordered: 79 VGPRs) at 1080p x 64 spp: 5 → 20.87, 6 → 20.65
 #endif
 #ifndef PT_W_BLOCK_WAVES
 #define PT_W_BLOCK_WAVES 1  // waves per workgroup (see PT_Q_BLOCK_WAVES)
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
-    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 2u);
+    float *slot = reinterpret_cast<float *>(s_xy + pixels_per_wave * 4u);
     uint32_t pix0 = 0;
     const uint32_t npix = live_take(fp, live_count, blockIdx.x * (uint32_t)PT_W_BLOCK_WAVES + wave, pixels_per_wave, pix0);
     const uint32_t count = fp.count, total = npix * count;
@@ -697,8 +707,12 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     if (lane < npix) {
         uint32_t x = 0, y = 0;
         (void)slot_to_pixel(fp, live[pix0 + lane], x, y);
-        s_xy[2 * lane] = x;
-        s_xy[2 * lane + 1] = y;
+        // (x, y, and the pixel's part of the two table index sums: rnd_base_v = (sample·2683 + x·3931 + y·2504)·3 and
+        // rnd_base_u = sample·2683 + x·3931 + y are linear in uint32 arithmetic, so a refill needs two multiplies, not five)
+        s_xy[4 * lane] = x;
+        s_xy[4 * lane + 1] = y;
+        s_xy[4 * lane + 2] = rnd_base_v(0u, x, y);
+        s_xy[4 * lane + 3] = rnd_base_u(0u, x, y);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -712,6 +726,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     const uint32_t root0 = sc.mesh_bvh_root[mesh0];
 
     const float inv_count = fp.inv_count;
+    const uint32_t count_log2 = (count & (count - 1u)) == 0u ? (uint32_t)__builtin_ctz(count) : 0xFFu;
     uint32_t next = 0;  // wave-uniform head of the queue
     bool active = false;
     int phase = 0;
@@ -737,48 +752,15 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     // every iteration takes samples off the queue, or moves every active lane on (a bounce, or up to
     // PT_WALK_STEPS nodes of a walk that visits each of the < 2^28 nodes at most 3 times)
     for (unsigned long long guard = ((unsigned long long)total + 1ull) * (RT_DEPTH + 2ull) * (3ull * (1ull << 28) / PT_WALK_STEPS + 4ull); guard; guard--) {
-        // ---- refill idle lanes from the queue
-        bool need = !active;
-        unsigned long long m = __ballot(need);
-        if (m && next < total) {
-            uint32_t cand = next + lanes_below(m);
-            if (need && cand < total) {
-                idx = cand;
-                uint32_t p = (uint32_t)(((float)idx + 0.5f) * inv_count);  // = idx / count exactly (pt_samples_q)
-                const uint32_t sample = fp.first + (idx - p * count);
-                float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
-                       q4 = rec[5 * p + 4];
-                const uint32_t gx = xy[2 * p], gy = xy[2 * p + 1];
-                bv = rnd_base_v(sample, gx, gy);
-                bu = rnd_base_u(sample, gx, gy);
-                uint32_t bits = __float_as_uint(q0.w);
-                if ((bits & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
-                    const float4 *lf = tree_leaf(fp.trees + __float_as_uint(q4.w), sc.table, bu);
-                    q0 = lf[0]; q1 = lf[1]; q2 = lf[2]; q3 = lf[3]; q4 = lf[4];
-                    bits = __float_as_uint(q0.w);
-                }
-                if ((bits & 0xFFu) == REC_FINAL) {  // a leaf of a tree, or count is not a multiple of g
-                    slot[3 * idx] = q3.x;
-                    slot[3 * idx + 1] = q3.y;
-                    slot[3 * idx + 2] = q3.z;
-                } else {
-                    depth = (bits >> 8) & 0xFFu;   // (type and extra_data of the record are the material's: re-read below)
-                    hn = xyz(q1);
-                    r.o = xyz(q0);
-                    r.d = xyz(q2);
-                    hmat = __float_as_uint(q2.w);
-                    out = xyz(q3);
-                    col = xyz(q4);
-                    active = true;
-                    phase = 0;
-                }
-            }
-            next += (uint32_t)__popcll(m);
-        }
-        if (!__any(active)) {
-            if (next >= total) break;
-            continue;
-        }
+        // Which lanes are inside a walk, and which want one of the cheap steps (the winner's record after a walk, a new
+        // sample from the queue, a material interaction + the primitives that are not models)?  The cheap steps are
+        // BATCHED: they run when at least PT_W_BATCH lanes want one (or nothing is walking) — run in every iteration
+        // they executed for the handful of lanes whose walks had just ended, at the price of a wave's whole issue time.
+        const bool walking = active && phase == 1;
+        const bool wants_cheap = (active && phase != 1) || (!active && next < total);
+        const uint32_t n_cheap = (uint32_t)__popcll(__ballot(wants_cheap));
+        const bool any_walk = __any(walking);
+        if (n_cheap == 0u && !any_walk) break;   // every path is through and the queue is empty
 #ifdef PT_WSTAT
         it_n++;
         it_active += __popcll(__ballot(active));
@@ -786,40 +768,129 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
         it_p1 += __popcll(__ballot(active && phase == 1));
         it_p2 += __popcll(__ballot(active && phase == 2));
 #endif
-        // ---- state 0: one material interaction, then the primitives that are not models
-        if (active && phase == 0) {
-            Rnd rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
-            Hit at;
-            at.p = r.o;
-            at.n = hn;
-            at.u = at.v = 0.0f;
-            at.tex = 0;
-            at.mat = hmat;
-            int type;
-            float extra;
-            V3 mcol;
-            load_material(c, hmat, type, extra, mcol);
-            scatter<false>(c, r, out, at, type, extra, col, rnd, false);
-            depth++;
-            if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
-                slot[3 * idx] = out.x;
-                slot[3 * idx + 1] = out.y;
-                slot[3 * idx + 2] = out.z;
-                active = false;
-            } else {
+        if (n_cheap >= PT_W_BATCH || !any_walk) {
+            // ---- state 2: the winner's record, its material
+            if (active && phase == 2) {
                 Nearest nb;
-                hit_primitives<false, true>(c, r, nb);
-                nb_t = nb.t;
-                nb_id = nb.id;
+                nb.t = nb_t;
+                nb.id = nb_id;
                 if (MULTI) {
-                    nb_face = nb_mat = 0;
-                    nb_u = nb_v = 0.0f;
+                    nb.face = nb_face;
+                    nb.mat = nb_mat;
+                    nb.u = nb_u;
+                    nb.v = nb_v;
+                } else if (wbest < faces0 && wt < RT_MAX_DISTANCE && wt < nb.t) {
+                    nb.t = wt;
+                    nb.id = K_MESH | mesh0;
+                    nb.face = wbest;
+                    nb.mat = mat0;
+                    nb.u = wu;
+                    nb.v = wv;
                 }
-                wpos = mesh_walk_start(root0);
-                wbest = faces0;
-                wt = wu = wv = 0.0f;
-                job = 0;
-                phase = 1;
+                V3 res;
+                bool done = false;
+                Hit h;
+                h.p = h.n = mk(0.0f, 0.0f, 0.0f);
+                h.u = h.v = 0.0f;
+                h.tex = h.mat = 0;
+                if (!hit_finish<false>(c, r, nb, h)) {
+                    res = mk(0.0f, 0.0f, 0.0f);
+                    done = true;
+                } else {
+                    int type;
+                    float extra;
+                    load_material(c, h.mat, type, extra, col);
+                    if (type == RT_LIGHT) {
+                        res = vmin(out, col);
+                        done = true;
+                    } else if (type == RT_TEXTURED) {
+                        col = texture_rgb(c.sc, h.u, h.v, h.tex);
+                    }
+                }
+                phase = 0;
+                if (done) {
+                    slot[3 * idx] = res.x;
+                    slot[3 * idx + 1] = res.y;
+                    slot[3 * idx + 2] = res.z;
+                    active = false;
+                } else {   // the next interaction happens here
+                    r.o = h.p;
+                    hn = h.n;
+                    hmat = h.mat;
+                }
+            }
+            // ---- refill idle lanes from the queue
+            bool need = !active;
+            unsigned long long m = __ballot(need);
+            if (m && next < total) {
+                uint32_t cand = next + lanes_below(m);
+                if (need && cand < total) {
+                    idx = cand;
+                    uint32_t p = count_log2 != 0xFFu ? idx >> count_log2 : (uint32_t)(((float)idx + 0.5f) * inv_count);  // = idx / count exactly (pt_samples_q)
+                    const uint32_t sample = fp.first + (idx - p * count);
+                    float4 q0 = rec[5 * p], q1 = rec[5 * p + 1], q2 = rec[5 * p + 2], q3 = rec[5 * p + 3],
+                           q4 = rec[5 * p + 4];
+                    bv = sample * 8049u + xy[4 * p + 2];   // = rnd_base_v(sample, x, y)
+                    bu = sample * 2683u + xy[4 * p + 3];   // = rnd_base_u(sample, x, y)
+                    uint32_t bits = __float_as_uint(q0.w);
+                    if ((bits & 0xFFu) == REC_TREE) {   // the pixel has a shared decision tree: this sample's leaf
+                        const float4 *lf = tree_leaf(fp.trees + __float_as_uint(q4.w), sc.table, bu);
+                        q0 = lf[0]; q1 = lf[1]; q2 = lf[2]; q3 = lf[3]; q4 = lf[4];
+                        bits = __float_as_uint(q0.w);
+                    }
+                    if ((bits & 0xFFu) == REC_FINAL) {  // a leaf of a tree, or count is not a multiple of g
+                        slot[3 * idx] = q3.x;
+                        slot[3 * idx + 1] = q3.y;
+                        slot[3 * idx + 2] = q3.z;
+                    } else {
+                        depth = (bits >> 8) & 0xFFu;   // (type and extra_data of the record are the material's: re-read below)
+                        hn = xyz(q1);
+                        r.o = xyz(q0);
+                        r.d = xyz(q2);
+                        hmat = __float_as_uint(q2.w);
+                        out = xyz(q3);
+                        col = xyz(q4);
+                        active = true;
+                        phase = 0;
+                    }
+                }
+                next += (uint32_t)__popcll(m);
+            }
+            // ---- state 0: one material interaction, then the primitives that are not models
+            if (active && phase == 0) {
+                Rnd rnd = fetch_rnd_b(sc.table, r.d, depth, bv, bu);
+                Hit at;
+                at.p = r.o;
+                at.n = hn;
+                at.u = at.v = 0.0f;
+                at.tex = 0;
+                at.mat = hmat;
+                int type;
+                float extra;
+                V3 mcol;
+                load_material(c, hmat, type, extra, mcol);
+                scatter<false>(c, r, out, at, type, extra, col, rnd, false);
+                depth++;
+                if (depth >= RT_DEPTH) {  // survived DEPTH bounces: returns what it has (:447,485)
+                    slot[3 * idx] = out.x;
+                    slot[3 * idx + 1] = out.y;
+                    slot[3 * idx + 2] = out.z;
+                    active = false;
+                } else {
+                    Nearest nb;
+                    hit_primitives<false, true>(c, r, nb);
+                    nb_t = nb.t;
+                    nb_id = nb.id;
+                    if (MULTI) {
+                        nb_face = nb_mat = 0;
+                        nb_u = nb_v = 0.0f;
+                    }
+                    wpos = mesh_walk_start(root0);
+                    wbest = faces0;
+                    wt = wu = wv = 0.0f;
+                    job = 0;
+                    phase = 1;
+                }
             }
         }
         // ---- state 1: a slice of the current job's mesh walk
@@ -861,56 +932,6 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 }
             }
         }
-        // ---- state 2: the winner's record, its material
-        if (active && phase == 2) {
-            Nearest nb;
-            nb.t = nb_t;
-            nb.id = nb_id;
-            if (MULTI) {
-                nb.face = nb_face;
-                nb.mat = nb_mat;
-                nb.u = nb_u;
-                nb.v = nb_v;
-            } else if (wbest < faces0 && wt < RT_MAX_DISTANCE && wt < nb.t) {
-                nb.t = wt;
-                nb.id = K_MESH | mesh0;
-                nb.face = wbest;
-                nb.mat = mat0;
-                nb.u = wu;
-                nb.v = wv;
-            }
-            V3 res;
-            bool done = false;
-            Hit h;
-            h.p = h.n = mk(0.0f, 0.0f, 0.0f);
-            h.u = h.v = 0.0f;
-            h.tex = h.mat = 0;
-            if (!hit_finish<false>(c, r, nb, h)) {
-                res = mk(0.0f, 0.0f, 0.0f);
-                done = true;
-            } else {
-                int type;
-                float extra;
-                load_material(c, h.mat, type, extra, col);
-                if (type == RT_LIGHT) {
-                    res = vmin(out, col);
-                    done = true;
-                } else if (type == RT_TEXTURED) {
-                    col = texture_rgb(c.sc, h.u, h.v, h.tex);
-                }
-            }
-            phase = 0;
-            if (done) {
-                slot[3 * idx] = res.x;
-                slot[3 * idx + 1] = res.y;
-                slot[3 * idx + 2] = res.z;
-                active = false;
-            } else {   // the next interaction happens here
-                r.o = h.p;
-                hn = h.n;
-                hmat = h.mat;
-            }
-        }
     }
     if (active) atomicOr(sc.walk_overflow, PT_OVF_WALK_SLICES);   // cold: the outer loop ended on its guard with a path unfinished
 #ifdef PT_WSTAT
@@ -934,7 +955,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 sum = sum + mk(sl[0], sl[1], sl[2]);
             }
         sum = group_sum(sum, g);
-        if (p < npix && l == 0) accumulate(accum, (size_t)xy[2 * p + 1] * fp.w + xy[2 * p], sum, count);
+        if (p < npix && l == 0) accumulate(accum, (size_t)xy[4 * p + 1] * fp.w + xy[4 * p], sum, count);
     }
 }
 
