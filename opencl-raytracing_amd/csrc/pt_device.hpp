@@ -859,12 +859,14 @@ template <bool COUNT, bool ACCEL>
 PT_DEV PixelRec trace_branch(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t max_stretch = RT_DEPTH) {
     PixelRec rec;
     rec.p_kind = rec.n_extra = rec.d = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t bounces = 0u;
     for (uint32_t i = i0; i < RT_DEPTH; i++) {
         Hit h;
         if (!hit_scene<COUNT, ACCEL>(c, r, h)) {
             out = mk(0.0f, 0.0f, 0.0f);
             break;
         }
+        bounces = i - i0 + 1u;
         if (COUNT) c.cn->c[CN_H_BOUNCE]++;
         int type;
         float extra;
@@ -892,13 +894,16 @@ PT_DEV PixelRec trace_branch(const Ctx &c, Ray r, V3 out, uint32_t i0, uint32_t 
         none.u = 0.0f;
         scatter<COUNT>(c, r, out, h, type, extra, col, none);
     }
-    rec.p_kind.w = __uint_as_float((uint32_t)REC_FINAL);
+    rec.p_kind.w = __uint_as_float((uint32_t)REC_FINAL | (bounces << 8));   // (how many hits the stretch went through: pt_prefix's load estimate)
     rec.out = make_float4(out.x, out.y, out.z, 0.0f);
     return rec;
 }
+#ifndef PT_PREFIX_STRETCH
+#define PT_PREFIX_STRETCH RT_DEPTH   // A/B: deterministic bounces pt_prefix follows before the samples take over (RT_DEPTH: to the end)
+#endif
 template <bool COUNT, bool ACCEL>
 PT_DEV PixelRec trace_prefix(const Ctx &c, Ray r, uint32_t gx, uint32_t gy) {
-    return trace_branch<COUNT, ACCEL>(c, r, mk(1.0f, 1.0f, 1.0f), 0u);
+    return trace_branch<COUNT, ACCEL>(c, r, mk(1.0f, 1.0f, 1.0f), 0u, PT_PREFIX_STRETCH);
 }
 
 // radiance of one sample continuing from its pixel's record

@@ -20,20 +20,35 @@ using namespace rtamd;
 
 // =============================== device kernels ===============================
 
-// wave (or pixel group) `unit` of a sample kernel → its segment, its first entry and how many of `want` exist.
-// Safe by construction, whatever the grid: the count is clamped to the segment's capacity, the unit's start is formed
-// in 64 bits and clamped INTO the list (start <= cnt), so `cnt - start` cannot wrap and `first + result` never leaves
-// the segment — a unit beyond the list gets 0 entries.  (Round 2's form `start < cnt ? min(want, cnt - start) : 0`
+// wave (or pixel group) `unit` of a sample kernel → its first entry in the live list and how many of `want` exist.
+// The list has two parts (pt_prefix): the HEAVY pixels, stored from the end of the capacity downwards, and the others,
+// stored from 0 upwards in the order in which pt_prefix's workgroups finish.  The heavy ones are taken FIRST (longest
+// processing time first — see pt_prefix), then the rest in list order.
+// Safe by construction, whatever the grid: the counts are clamped to the list's capacity, a unit's start is formed
+// in 64 bits and clamped INTO its part (start <= count), so `count - start` cannot wrap and `first + result` never
+// leaves the part — a unit beyond the list gets 0 entries.  (Round 2's form `start < cnt ? min(want, cnt - start) : 0`
 // is the same function, but an experiment that inlined it into a persistent loop faulted and the cause was never
 // established beyond "the guard was optimised away"; this form has no guard to lose.  tests/test_gpu_properties.py
 // ::test_live_list_far_shorter_than_the_grid renders an all-sky frame and a frame with ONE live pixel.)
 PT_DEV uint32_t live_take(const FrameParams &fp, const uint32_t *__restrict__ live_count, uint32_t unit, uint32_t want,
                           uint32_t &first) {
-    const uint32_t seg = unit % LIVE_SEGMENTS;
-    const uint32_t cnt = min(live_count[seg * LIVE_COUNT_STRIDE], fp.seg_cap);
-    const unsigned long long start64 = (unsigned long long)(unit / LIVE_SEGMENTS) * want;
+    const uint32_t cap = fp.seg_cap;
+    const uint32_t cnt_l = min(live_count[0], cap);
+    const uint32_t cnt_h = min(live_count[LIVE_HEAVY_COUNTER], cap - cnt_l);
+    const uint32_t units_h = want ? (cnt_h + want - 1u) / want : 0u;
+    const bool heavy = unit < units_h;
+    const uint32_t cnt = heavy ? cnt_h : cnt_l;
+    const unsigned long long start64 = (unsigned long long)(heavy ? unit : unit - units_h) * want;
     const uint32_t start = (uint32_t)min(start64, (unsigned long long)cnt);
-    first = seg * fp.seg_cap + start;
+    first = (heavy ? cap - cnt_h : 0u) + start;
+#ifdef PT_EXP_SKIP   // timing experiment (wrong image): leave out the last (1) / first (2) 3 % of the light list's chunks
+    {
+        const uint32_t nl = want ? (cnt_l + want - 1u) / want : 0u, c = unit - units_h;
+        if (!heavy && PT_EXP_SKIP == 1 && c >= nl - nl / 32u) return 0u;
+        if (!heavy && PT_EXP_SKIP == 2 && c < nl / 32u) return 0u;
+        if (!heavy && PT_EXP_SKIP == 3 && c >= nl / 2u && c < nl / 2u + nl / 32u) return 0u;
+    }
+#endif
     return min(want, cnt - start);
 }
 
@@ -155,7 +170,6 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     uint32_t x = 0, y = 0;
     bool valid = slot < fp.slot_end && slot_to_pixel(fp, slot, x, y);
     bool is_live = false;
-    uint32_t glass_pos = 0u;
     PixelRec rec;
     rec.p_kind = rec.n_extra = rec.d = rec.out = rec.col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (valid) {
@@ -175,31 +189,46 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
             is_live = true;
         }
     }
-    // append live pixels — slot index and record, both at the pixel's position in the live list, so the
-    // sample kernels read records without an indirection.  ONE atomic per WORKGROUP: the four waves' counts meet
-    // in LDS, thread 0 reserves the workgroup's run, each wave takes its part of it.  (One atomic per wave made
-    // 32 400 waves of a 1080p frame queue on a single address: 0.12 of the kernel's 0.20 ms.  Spreading the list
-    // over LIVE_SEGMENTS > 1 independent counters removes the queue too, but costs pt_samples_q 13–26 %: the
-    // list's ORDER matters to it — see LIVE_SEGMENTS.)  Order within the list is irrelevant to the result.
+    // Append the live pixels — slot index and record, both at the pixel's position in the live list, so the sample
+    // kernels read records without an indirection.  Order within the list is irrelevant to the result but NOT to the
+    // speed of the sample kernel, whose waves take the list chunk by chunk in launch order, a wave living as long as
+    // its longest path:
+    //  * the pixels of a HEAVY workgroup — one in which some pixel's path went through two or more mirror / glass
+    //    bounces, or met glass as its first random event: the neighbourhood of mirrors and glass, where samples get
+    //    trapped for many bounces whatever their own first vertex is — are stored from the END of the capacity
+    //    downwards and taken FIRST (longest processing time first).  In completion order they sat at the end of the
+    //    list (their workgroups finish last) and, started last, WERE the sample kernel's tail: leaving out the last
+    //    3 % of the list's chunks made C2's frame 10.6 % shorter, the first 3 % 3.6 %, 3 % in the middle 1.8 %
+    //    (profiles/r03_experiments.md);
+    //  * the others from 0 upwards in the order in which the workgroups finish — consecutive chunks are neighbouring
+    //    pixels: dealing the list out in strands costs 10–55 % (texel and table locality).
+    // ONE atomic per WORKGROUP either way: the four waves' counts meet in LDS, thread 0 reserves the workgroup's run,
+    // each wave takes its part of it (one atomic per wave made 32 400 waves of a 1080p frame queue on a single
+    // address: 0.12 of the kernel's 0.20 ms).
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t kb = __float_as_uint(rec.p_kind.w);
+    // (bits 8..15: the vertex's bounce index = mirror / glass bounces before it; a final colour's: hits on its way)
+    const bool lane_heavy = valid && (((kb >> 8) & 0xFFu) >= 2u || is_glass_vertex(rec));
+    const bool wg_heavy = __syncthreads_or(lane_heavy ? 1 : 0) != 0;
     __shared__ uint32_t s_wave_n[4], s_base;
     unsigned long long m = __ballot(is_live);
     if (lane == 0) s_wave_n[wv] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
-        s_base = total ? atomicAdd(&live_count[(blockIdx.x % LIVE_SEGMENTS) * LIVE_COUNT_STRIDE], total) : 0u;
+        s_base = total ? atomicAdd(&live_count[wg_heavy ? LIVE_HEAVY_COUNTER : 0u], total) : 0u;
     }
     __syncthreads();
+    uint32_t pos = 0u;
     if (is_live) {
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; k++) before += s_wave_n[k];
-        uint32_t pos = (blockIdx.x % LIVE_SEGMENTS) * fp.seg_cap + s_base + before +
-                       lanes_below(m);
+        pos = s_base + before + lanes_below(m);
+        if (wg_heavy) pos = fp.seg_cap - 1u - pos;
         live[pos] = slot;
         recs[pos] = rec;
-        glass_pos = pos;
     }
+    const uint32_t glass_pos = pos;
     // Pixels whose first random event is a dielectric surface are listed for pt_tree_pass (one atomic per wave): their
     // two continuations through the glass are traced once per pixel there instead of once per sample.
     {
@@ -1199,7 +1228,8 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         auto launch_samples = [&](hipStream_t st, const PixelRec *l_recs, const uint32_t *l_live, const uint32_t *l_count, uint32_t l_cap) {
             FrameParams fl = fp;
             fl.seg_cap = l_cap;
-            auto units = [&](uint32_t per_unit) { return LIVE_SEGMENTS * ((l_cap + per_unit - 1) / per_unit); };
+            // (the two parts of the list each end in a partial chunk: one unit more than capacity / chunk)
+            auto units = [&](uint32_t per_unit) { return (l_cap + per_unit - 1) / per_unit + 1u; };
             dim3 gridq((units(ppw) + PT_Q_BLOCK_WAVES - 1) / PT_Q_BLOCK_WAVES);
             dim3 grid2((unsigned)((((uint64_t)units(1u) << glog2) + 255) / 256));
 #define PT_CALL_QUEUE_W(C, A, G, W) \

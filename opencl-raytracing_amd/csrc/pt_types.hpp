@@ -161,6 +161,7 @@ struct FrameParams {
 #define LIVE_SEGMENTS 1u
 #endif
 #define LIVE_COUNT_STRIDE 32u   // counters 128 bytes apart: one L2 line each
+#define LIVE_HEAVY_COUNTER 24u   // word of the live-count block: how many HEAVY pixels pt_prefix stored from the end of the list downwards
 #define LIVE_TREE_COUNTER 16u   // words of the live-count block (zeroed with it): [16] glass-first pixels = trees, [17], [18] the work of levels 1, 2
 
 // Counters are spread over COUNTER_REPLICAS rows (one per workgroup residue) so
