@@ -78,3 +78,53 @@ def test_random_scene_bit_exact(seed, oracle, table):
     exp_lin = (exp_sum / np.float32(spp)).astype(np.float32)
     assert np.array_equal(frames[0][..., :3].view(np.uint32), exp_lin.view(np.uint32))
     t.close()
+
+
+# ---- the same random scenes under the ROCm-OpenCL arithmetic policies, against the reference's gfx950 OpenCL code objects
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(cases.ROOT, "oracle"))
+import oracle as orc  # noqa: E402
+
+_HSACO = {1: orc.REF950_HSACO_NOCONTRACT, 2: orc.REF950_HSACO}
+
+
+@pytest.mark.skipif(not (orc.ReferenceGfx950.available() and orc.ReferenceGfx950.available(orc.REF950_HSACO_NOCONTRACT)),
+                    reason="oracle/_ref_gfx950 (gfx950 builds of the reference) not present")
+@pytest.mark.parametrize("seed", list(range(201, 217)))
+def test_random_scene_bit_exact_against_the_rocm_opencl_build(seed):
+    """Arbitrary scenes (spheres below and above the BVH threshold, planes, lenses, meshes below and above theirs, every
+    material kind — textured turned diffuse: no OpenCL image object from HIP), policies 1 and 2 alternating: every pixel
+    of samples 0-2 of the frame bit-identical to the reference kernel file as ROCm's OpenCL tool chain builds it, with
+    the acceleration structures on and off; the fused frame within 1e-4."""
+    policy = 1 + seed % 2
+    s, cam = random_scene(seed)
+    s.materials["type"][s.materials["type"] == A.T_TEXTURED] = A.T_DIFFUSE
+    s.textures = None
+    W, H, spp = 96, 54, (64 if seed % 3 == 0 else 8)
+    ref = orc.ReferenceGfx950(_HSACO[policy])
+    t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
+    t.setArith(policy)
+    t.resetCounters()
+    table = t.getRandomTable()
+    for k in range(3):
+        _, last = ref.render(s, cam, table, W, H, k, 1, want_last=True)
+        for accel in (1, 0):
+            t.setOption(t.OPT_ACCEL, accel)
+            t.clear()
+            t.renderSamples(cam, k, 1)
+            t.sync()
+            mine = t.readLinear()[..., :3]
+            same = (mine.view(np.uint32) == last[..., :3].view(np.uint32)).all(axis=2)
+            assert same.all(), (seed, policy, k, accel, int((~same).sum()))
+    t.setOption(t.OPT_ACCEL, 1)
+    a = ref.render(s, cam, table, W, H, 0, spp)[..., :3].astype(np.float64) / spp
+    t.clear()
+    t.renderSamples(cam, 0, spp)
+    t.sync()
+    b = t.readLinear()[..., :3].astype(np.float64)
+    rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+    assert rel.max() <= 1e-4, rel.max()
+    assert t.walkOverflow() == 0
+    t.close()
