@@ -13,9 +13,12 @@ block and random table are resident in HBM before the timed region.
 
 Workload: ONE workload along the whole N curve — C2 by default, the configuration the metric is quoted on
 (8 spheres + plane, 1920x1080, 64 spp).
-  C2 / C3 (frames of milliseconds)  WEAK scaling: every pixel gets 64 x N samples, issued as N fused calls of 64, the
-            frame's 8x8 tiles interleaved over the ranks — each GPU traces the pixel-samples of one N = 1 frame with
-            the very kernels of the N = 1 line, then the packed tiles meet on rank 0.
+  C2 / C3 (frames of milliseconds)  WEAK scaling: every pixel gets 64 x N samples in ONE fused call per rank, the
+            frame's 8x8 tiles interleaved over the ranks — each GPU traces the pixel-samples of one N = 1 frame (an
+            N-th of the pixels, N times the samples) with the kernels of the N = 1 line, then the packed tiles meet on
+            rank 0.  (One call, not N calls of 64: a launch over an N-th of the pixels is mostly tail — measured on one
+            GPU, tools/shard_chunk_probe.py: the rank-0 share of an 8-rank step takes 3.44 ms as 8 calls of 64 samples,
+            1.42 ms as one call of 512.)
   C4 / C5 (BASELINE's tile-sharded configurations, frames of 0.1 ... 1 s)  STRONG scaling: the same frame cut over the ranks.
 Every N > 1 line also carries the same workload's single-GPU step (rank 0 alone, same run, untimed leg) and
 `speedup_vs_1gpu_same_workload`, so the curve can be read from one line.
@@ -323,7 +326,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC),
                     help="default c2, the configuration the metric is quoted on — at every N")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
-                    help="N > 1: auto = weak for c2 / c3 (64 x N spp in N calls of 64), strong for c4 / c5 (the same frame sharded)")
+                    help="N > 1: auto = weak for c2 / c3 (64 x N spp in one call per rank), strong for c4 / c5 (the same frame sharded)")
     ap.add_argument("--size", default="", metavar="WxH", help="override the frame size, e.g. 1920x1080")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--arith", default="rocm-opencl", choices=sorted(ARITH),
@@ -370,7 +373,7 @@ def main():
     base_spp = args.spp or wl.spp
     wl.spp = base_spp
     spp = base_spp * world if scaling == "weak" else base_spp
-    chunk = base_spp                                 # samples per fused call: the kernels of the N = 1 line
+    chunk = spp if spp <= 512 else base_spp          # samples per fused call: ONE call per step (a wave's queue holds up to 512 samples)
     key = profile_key(workload, wl.width, wl.height, base_spp)
     tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
     tracer.setArith(args.arith)

@@ -88,7 +88,9 @@ class GpuShard:
 
     def __init__(self, tracer, rank, world, tile=TILE, chunk=None):
         """``chunk``: samples per fused trace call (None = all in one call).  bench.py's weak-scaling run gives
-        every pixel 64·N samples as N calls of 64, so each rank runs the kernels of the single-GPU line."""
+        every pixel 64·N samples in ONE call per rank (a launch over an N-th of the pixels is mostly tail: N calls of 64
+        cost a rank 3.4 ms at N = 8, one call of 512 costs 1.4 ms — tools/shard_chunk_probe.py); above 512 samples per
+        pixel (the capacity of a wave's sample queue) it falls back to calls of the base sample count."""
         import torch
         self.torch = torch
         self.tracer, self.rank, self.world, self.chunk = tracer, rank, world, chunk

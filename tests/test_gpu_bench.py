@@ -98,10 +98,10 @@ def _two_ranks(extra, port=None, plain=False):
 def test_bench_plain_gpus_2_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment — the form of the driver's N = 1 command: the ranks are
     started as a child process and its one JSON line comes back.  Default workload at every N: C2, weak scaling (64 x N
-    spp in N calls of 64: the kernels of the N = 1 line)."""
+    spp per pixel in one fused call per rank)."""
     j = _two_ranks([], plain=True)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["workload"].startswith("C2")
-    assert j["config"]["spp_total"] == 128 and j["config"]["spp_per_call"] == 64
+    assert j["config"]["spp_total"] == 128 and j["config"]["spp_per_call"] == 128
     assert j["config"]["pixel_samples_per_step"] == 1920 * 1080 * 128
     assert j["single_gpu_same_workload"]["ms_per_step"] > 0 and j["speedup_vs_1gpu_same_workload"] > 0
     assert j["cpu_baseline"]["value"] > 0 and j["walk_overflow"] == 0
