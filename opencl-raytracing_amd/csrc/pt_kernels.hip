@@ -690,6 +690,20 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
                         // 1 → 20.87 ms, 8 → 21.14, 16 → 21.41, 24 → 21.79, 32 → 22.42 (16 with slices of 12 / 8 nodes: 20.79 / 21.01):
                         // waiting lanes cost more than sparsely filled cheap steps — batching stays off
 #endif
+// The root of the (single) mesh is tested while the lane is still in state 0: a ray that misses the whole mesh (a third of
+// C5's walks) goes straight to state 2 instead of idling through a slice, and the cheap states repeat (at most
+// PT_W_CHEAP_REPEATS times) while at least PT_W_CHEAP_AGAIN lanes came out of them with no walk to join.  C5 at 4K x 512 spp:
+// off 561.8 ms, root test without repeats 571.6, repeats from 4 / 8 / 16 lanes 548.6 / 546.6 / 545.6.  (Ending a slice early once
+// 8 / 16 / 24 of its lanes are through: 593.7 / 558.8 / 553.4 vs 548.2 — the fixed slice stays.)
+#ifndef PT_W_ROOT_FIRST
+#define PT_W_ROOT_FIRST 1
+#endif
+#ifndef PT_W_CHEAP_AGAIN
+#define PT_W_CHEAP_AGAIN 8u
+#endif
+#ifndef PT_W_CHEAP_REPEATS
+#define PT_W_CHEAP_REPEATS 4u
+#endif
 #ifndef PT_W_WAVES
 #define PT_W_WAVES 6  // A/B on C5 at 16 spp (round 2, 92 VGPRs): 4 → 116.5 ms, 5 → 110.2, 6 → 116.1 (spills); round 3 (the loop reordered: 79 VGPRs) at 1080p x 64 spp: 5 → 20.87, 6 → 20.65
 #endif
@@ -798,6 +812,9 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
         it_p2 += __popcll(__ballot(active && phase == 2));
 #endif
         if (n_cheap >= PT_W_BATCH || !any_walk) {
+          // (PT_W_ROOT_FIRST: a ray that misses the mesh's root goes from state 0 straight to state 2; the cheap states
+          // repeat while at least PT_W_CHEAP_AGAIN lanes came out of them without a walk to join)
+          for (uint32_t again = 0;; again++) {
             // ---- state 2: the winner's record, its material
             if (active && phase == 2) {
                 Nearest nb;
@@ -919,8 +936,21 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                     wt = wu = wv = 0.0f;
                     job = 0;
                     phase = 1;
+#if PT_W_ROOT_FIRST
+                    if (!MULTI) {
+                        wpos = mesh_walk_first(sc, r, root0, faces0);
+                        if (wpos.cur == PT_MESH_END) phase = 2;
+                    }
+#endif
                 }
             }
+#if PT_W_ROOT_FIRST
+            if (MULTI || again >= PT_W_CHEAP_REPEATS) break;
+            if ((uint32_t)__popcll(__ballot((active && phase != 1) || (!active && next < total))) < PT_W_CHEAP_AGAIN) break;
+#else
+            break;
+#endif
+          }
         }
         // ---- state 1: a slice of the current job's mesh walk
         if (active && phase == 1) {
@@ -1000,6 +1030,16 @@ __global__ __launch_bounds__(256) void pt_probe(DeviceScene sc, FrameParams fp, 
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     Ray r0 = primary_ray(fp.cam, xs[i], ys[i], fp.w, fp.h);
+#ifdef PT_PROBE_NODES  // diagnostic build (tools/walk_hist.py): the probe returns (BVH nodes tested, mesh walks, bounces) of the sample
+    LaneCounters cn;
+    zero_counters(cn);
+    c.cn = &cn;
+    (void)radiance<true, ACCEL>(c, r0, ss[i], xs[i], ys[i]);
+    out[3 * i] = (float)cn.c[CN_DBG_BVH_NODES];
+    out[3 * i + 1] = (float)cn.c[CN_T_MESH];
+    out[3 * i + 2] = (float)cn.c[CN_BOUNCES];
+    return;
+#endif
     V3 col = radiance<false, ACCEL>(c, r0, ss[i], xs[i], ys[i]);
     out[3 * i] = col.x;
     out[3 * i + 1] = col.y;

@@ -260,6 +260,22 @@ PT_DEV bool mesh_bvh_steps(const DeviceScene &sc, const Ray &r, MeshWalk &w, uin
     return cur == PT_MESH_END;
 }
 
+// The first step of a search on its own (pt_samples_w tests the root while the lane is still in its cheap state: a ray
+// that misses the whole mesh never joins a walk slice).  Same node test, same outcome as the first step of mesh_bvh_steps.
+PT_DEV MeshWalk mesh_walk_first(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t best_face) {
+    const MeshCull k = mesh_cull_setup(r);
+    const float4 *nd = at32(sc.mbvh_nodes, root * 48u);
+    float4 a = nd[0], cn = nd[1], pk = nd[2];
+    const uint32_t B = __float_as_uint(cn.w);
+    const uint32_t p0 = __float_as_uint(pk.x), p1 = __float_as_uint(pk.y), p2 = __float_as_uint(pk.z);
+    const float sin_a = half_hi(p1);
+    float4 b = make_float4(half_lo(p0), half_hi(p0), half_lo(p1), cn.w);
+    float4 ex = make_float4(sin_a, pk.w, half_lo(p2), half_hi(p2));
+    cn.w = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-sin_a, sin_a, 1.0f)));
+    if (mesh_node_miss<0>(r, k, a, b, cn, ex, best_face, nullptr)) return MeshWalk{__float_as_uint(a.w) & PT_MESH_END};
+    return MeshWalk{(B & 0x80000000u) ? (root | PT_MESH_PARKED) : B};
+}
+
 template <int MODE>
 PT_DEV uint32_t mesh_bvh_walk(const DeviceScene &sc, const Ray &r, uint32_t root, uint32_t &best_face, float &ft,
                               float &fu, float &fv, LaneCounters *dbg = nullptr) {

@@ -36,7 +36,9 @@ struct DevBuf {
 namespace pt { struct KernelSet; }
 
 #define ACCEL_MIN_SPHERES 64
+#ifndef MESH_BVH_MIN_FACES
 #define MESH_BVH_MIN_FACES 32
+#endif
 
 struct rt_context {
     int device = 0;
