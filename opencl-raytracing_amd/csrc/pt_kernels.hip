@@ -567,11 +567,16 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
             continue;  // every candidate was a final-colour pixel: keep draining the queue
         }
         PT_STAMP(c, 0);
-#ifdef PT_EXP_PAD  // timing experiment: PT_EXP_PAD extra independent full-rate VALU instructions per iteration — an
-                   // issue-bound loop slows down in proportion, a latency-bound one does not
-#pragma unroll
-        for (int k = 0; k < PT_EXP_PAD / 4; k++)
-            asm volatile("v_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0\n\tv_or_b32 %0, %0, %0" : "+v"(idx));  // identity on a live register: no extra VGPR
+#ifdef PT_EXP_PAD  // timing experiment (tools/pad_experiment.sh): PT_EXP_PAD extra full-rate VALU instructions per iteration
+                   // (v_or_b32 x, x, x on a live register: no new VGPR; PT_EXP_PAD_NOP: operand-free v_nop instead).  An
+                   // issue-bound loop slows down by their issue time, a latency-bound one does not (profiles/r03_experiments.md)
+#define PT_STR2(x) #x
+#define PT_STR(x) PT_STR2(x)
+#ifdef PT_EXP_PAD_NOP
+        asm volatile(".rept " PT_STR(PT_EXP_PAD) "\n\tv_nop\n\t.endr");
+#else
+        asm volatile(".rept " PT_STR(PT_EXP_PAD) "\n\tv_or_b32 %0, %0, %0\n\t.endr" : "+v"(idx));
+#endif
 #endif
 #ifdef PT_QSTAT  // diagnostic: lane-iterations used / offered (read through rt_get_debug_counters on a BVH-free scene)
         if (COUNT) {

@@ -120,6 +120,7 @@ __device__ __forceinline__ bool lane_on(int mask) {
 #define I_PK_FMA_F32(i) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(d##i) : "v"(db));
 #define I_READFIRSTLANE(i) asm volatile("v_readfirstlane_b32 s20, %0" : : "v"(a##i) : "s20");
 #define I_S_NOP(i) asm volatile("s_nop 0");
+#define I_V_NOP(i) asm volatile("v_nop");
 #define I_S_ADD(i) asm volatile("s_add_u32 s20, s20, 1" : : : "s20", "scc");
 #define I_CNDMASK_VCC(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(b));   // vcc set before the loop, not clobbered
 #define I_CMP_E64(i) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(a##i), "v"(b) : "s20", "s21");
@@ -209,6 +210,7 @@ DEF_KERNEL(mov_distinct, I_MOV_DISTINCT)
 DEF_KERNEL(fmac_f32, I_FMAC_F32)
 DEF_KERNEL(cmp_class, I_CMP_CLASS)
 DEF_KERNEL(floor_f32, I_FLOOR_F32)
+DEF_KERNEL(v_nop, I_V_NOP)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_ds_b128_bcast(const float *seed, Out *out, float *sink, int loops, int mask) {
@@ -283,7 +285,7 @@ int main() {
         {"v_bfe_u32", k_bfe_u32, 1}, {"v_min_f32", k_min_f32, 1}, {"v_min_u32", k_min_u32, 1},
         {"v_max3_u32", k_max3_u32, 1}, {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_sub_f32", k_sub_f32, 1},
         {"v_xor_b32", k_xor_b32, 1}, {"v_mov_b32 (distinct sources)", k_mov_distinct, 1}, {"v_fmac_f32", k_fmac_f32, 1},
-        {"v_cmp_class_f32", k_cmp_class, 1}, {"v_floor_f32", k_floor_f32, 1},
+        {"v_cmp_class_f32", k_cmp_class, 1}, {"v_floor_f32", k_floor_f32, 1}, {"v_nop", k_v_nop, 1},
     };
     const int waves_per_simd[] = {1, 2, 4, 6, 8};
     const int loops = 400;
