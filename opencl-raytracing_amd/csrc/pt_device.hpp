@@ -41,6 +41,9 @@ namespace PT_NS {
 #endif                     // (ds_read_b128 broadcast) instead of scalar loads; measured slower, DESIGN.md §5
 #define PT_LDS_SPHERE_CAP 256
 
+#ifndef PT_FACE_MASK
+#define PT_FACE_MASK 1  // face-scanned meshes of <= 32 faces: facing test first, per-lane candidate lists (hit_models)
+#endif
 #ifndef PT_NO_MODELS
 #define PT_NO_MODELS 0  // experiment: compile the mesh code out
 #endif
@@ -80,6 +83,7 @@ struct Ctx {
     const float4 *lsph = nullptr;  // PT_LDS_SPHERES: LDS copy of sph4 (or nullptr)
     LdsV4 lwin = nullptr;  // LDS winner records of small sphere sets (stage_materials), or nullptr
     LdsV4 lpln = nullptr;  // LDS (normal, mat) of small plane sets, or nullptr
+    LdsV4 lfaces = nullptr;  // LDS copy of DeviceScene::faces (scenes of a few small meshes; pt_samples_q), or nullptr
 #if PT_STAMPS
     mutable unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     mutable unsigned long long st_last = 0;
@@ -564,9 +568,50 @@ PT_DEV void hit_models(const Ctx &c, const Ray &r, Nearest &nb) {
                     c.cn->c[CN_H_TRI] += mesh_bvh_walk<1>(sc, r, root, lim, x0, x1, x2) + (found ? 1u : 0u);
                 }
             }
-            const float4 *fr = sc.faces + 3u * (size_t)sc.mesh_face_base[mi];
+            const uint32_t fbase = sc.mesh_face_base[mi];
+            const float4 *fr = sc.faces + 3u * (size_t)fbase;
+            bool scan = root == PT_MESH_BVH_NONE;
+#if PT_FACE_MASK
+            if (!COUNT && scan && mesh.face_count <= 32u) {
+                // Small mesh: the facing test first.  `dot(n, d) < 0` (:298) needs only the stored normal — one scalar
+                // load and a dot product per face — and rules out every face on the far side of a closed mesh (half of
+                // a cube's).  Each lane then runs hitTriangle on ITS OWN front-facing faces in ascending order and stops
+                // at its first hit: the same face as the scan's (both conditions must hold, in either order), in half
+                // the passes.  The records of a lane's face are gathered per lane (a few hundred bytes, cache resident).
+                scan = false;
+                uint32_t cand = 0;
+                for (uint32_t f = 0; f < mesh.face_count; f++) {
+                    const float4 n4 = fr[3u * f + 2u];
+                    if (dot(mk(n4.y, n4.z, n4.w), r.d) < 0.0f) cand |= 1u << f;
+                }
+                while (cand) {
+                    const uint32_t f = (uint32_t)__builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    float4 g0, g1;
+                    float e2z;
+                    if (c.lfaces) {   // staged: three LDS reads (a per-lane gather from memory costs as much address-path time as it saves)
+                        const uint32_t at = 3u * (fbase + f);
+                        g0 = lds_ld(c.lfaces, at);
+                        g1 = lds_ld(c.lfaces, at + 1u);
+                        e2z = lds_ld(c.lfaces, at + 2u).x;
+                    } else {
+                        const float4 *q = fr + 3u * f;
+                        g0 = q[0];
+                        g1 = q[1];
+                        e2z = q[2].x;
+                    }
+                    float u, v;
+                    float t = triangle_t(r, mk(g0.x, g0.y, g0.z), mk(g0.w, g1.x, g1.y), mk(g1.z, g1.w, e2z), &u, &v);
+                    if (t < PT_MISS) {
+                        found = true;
+                        ft = t; fu = u; fv = v; fface = f;
+                        cand = 0;
+                    }
+                }
+            }
+#endif
             float4 q0 = fr[0], q1 = fr[1], q2 = fr[2];
-            for (uint32_t f = 0; root == PT_MESH_BVH_NONE && f < mesh.face_count; f++) {
+            for (uint32_t f = 0; scan && f < mesh.face_count; f++) {
                 fr += 3;  // the array ends with a dummy record, so this prefetch stays in bounds
                 float4 p0 = fr[0], p1 = fr[1], p2 = fr[2];
                 if (!found) {  // a lane that has its face idles while the others keep scanning

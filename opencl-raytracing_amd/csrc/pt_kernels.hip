@@ -434,6 +434,9 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
     }
     return p < 1u ? 1u : p;
 }
+#ifndef PT_LDS_FACE_CAP
+#define PT_LDS_FACE_CAP 64u   // faces (48 bytes each) of a scene of small meshes that may be staged in LDS (launch_fused)
+#endif
 #ifndef PT_Q_BLOCK_WAVES
 #define PT_Q_BLOCK_WAVES 1  // waves per workgroup of pt_samples_q (they share only the staged materials): a wave that is through frees
                             // its LDS and wave slot at once instead of waiting for three others (A/B on C2: 4 → 2.42 ms, 2 → 2.42, 1 → 2.34)
@@ -458,6 +461,12 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
 #if PT_LDS_SPHERES
     c.lsph = stage_spheres(sc, s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count));
 #endif
+    if (GEOM != 0 && fp.lds_face_f4) {   // the face records of a scene of a few small meshes (hit_models' candidate loop)
+        float4 *s_faces = s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count);
+        for (uint32_t i = threadIdx.x; i < fp.lds_face_f4; i += blockDim.x) s_faces[i] = sc.faces[i];
+        __syncthreads();
+        c.lfaces = lds_ptr(s_faces);
+    }
 
 #if PT_Q_BLOCK_WAVES == 1
     const uint32_t wave = 0u, lane = threadIdx.x;
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(64 * PT_Q_BLOCK_WAVES, WAVES) void pt_samples_q(Dev
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 #endif
     char *wave_lds = reinterpret_cast<char *>(s_dyn + lds_static_used(sc.material_count, sc.sphere_count, sc.plane_count) +
-                                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0)) +
+                                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0) + (GEOM != 0 ? fp.lds_face_f4 : 0u)) +
                      (size_t)wave * queue_wave_lds_bytes(pixels_per_wave, fp.count);
     float4 *s_rec = reinterpret_cast<float4 *>(wave_lds);
     uint32_t *s_xy = reinterpret_cast<uint32_t *>(s_rec + pixels_per_wave * 5u);
@@ -1242,6 +1251,18 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         const bool simple_geom = sc.lens_count == 0 && sc.model_count == 0;   // spheres and planes only
         const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
         uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
+        // Face records in LDS for hit_models' candidate loop: scenes whose meshes are all face-scanned (no mesh BVH) and
+        // hold at most PT_LDS_FACE_CAP faces together, and only when the copy fits into what the 1 KiB allocation granule
+        // leaves over anyway (C3: 576 bytes of a cube into 609 spare ones) — never at the price of a pixel per wave.
+        fp.lds_face_f4 = 0u;
+        if (PT_FACE_MASK && !simple_geom && sc.mesh_bvh_root == nullptr && !ctx->count_enabled) {
+            const size_t nf = ctx->h_faces.size() / 3u - (ctx->h_faces.empty() ? 0u : 1u);   // (the array ends with one dummy record)
+            if (nf > 0 && nf <= PT_LDS_FACE_CAP &&
+                queue_pixels_per_wave(count, q_waves, static_f4 + 3u * (uint32_t)nf, PT_Q_BLOCK_WAVES) == ppw) {
+                fp.lds_face_f4 = 3u * (uint32_t)nf;
+                static_f4 += fp.lds_face_f4;
+            }
+        }
         dim3 blockq(64 * PT_Q_BLOCK_WAVES);
         bool queue = ctx->sample_queue && count <= QUEUE_SLOTS;
         size_t lds_q = static_f4 * sizeof(float4) + PT_Q_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw, count);

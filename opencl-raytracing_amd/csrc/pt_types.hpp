@@ -148,6 +148,7 @@ struct FrameParams {
     uint32_t *glass;                // live-list positions of the pixels whose first random event is a dielectric surface
     uint32_t *tree_count;           // how many pt_prefix listed (tree i belongs to glass[i])
     uint32_t tree_cap;              // capacity of `trees` (0: trees off — RT_OPT_PREFIX_TREE, counting builds)
+    uint32_t lds_face_f4;           // pt_samples_q: float4 of DeviceScene::faces staged in LDS after the static tables (0: none; see launch_fused)
 };
 
 // The live list (pixels that need per-sample work) can be kept in LIVE_SEGMENTS independent segments, workgroup b

@@ -208,6 +208,7 @@ inline FrameParams frame_params(const rt_context *ctx, const float cam[12], uint
     fp.glass = nullptr;
     fp.tree_count = nullptr;
     fp.tree_cap = 0;
+    fp.lds_face_f4 = 0;
     {
         volatile float c = (float)count;
         volatile float q = 1.0f / c;

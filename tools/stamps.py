@@ -7,6 +7,7 @@ import opencl_raytracing_amd as rt
 rt.load_library(sys.argv[1])
 wl = rt.workloads.get(sys.argv[2] if len(sys.argv) > 2 else "c2")
 t = rt.RayTracer(wl.width, wl.height, scene=wl.scene)
+t.setArith(int(os.environ.get("RT_ARITH", "2")))   # the policy bench.py times
 t.clear(); t.renderSamples(wl.camera, 0, wl.spp); t.sync()
 t.debugCounters()
 t.close()
