@@ -572,7 +572,7 @@ PT_DEV void hit_models(const Ctx &c, const Ray &r, Nearest &nb) {
             const float4 *fr = sc.faces + 3u * (size_t)fbase;
             bool scan = root == PT_MESH_BVH_NONE;
 #if PT_FACE_MASK
-            if (!COUNT && scan && mesh.face_count <= 32u) {
+            if (!COUNT && !ACCEL && scan && mesh.face_count <= 32u) {   // (instantiations that also carry the mesh walk keep the scan: registers)
                 // Small mesh: the facing test first.  `dot(n, d) < 0` (:298) needs only the stored normal — one scalar
                 // load and a dot product per face — and rules out every face on the far side of a closed mesh (half of
                 // a cube's).  Each lane then runs hitTriangle on ITS OWN front-facing faces in ascending order and stops

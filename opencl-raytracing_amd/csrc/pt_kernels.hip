@@ -401,7 +401,8 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #define PT_Q_WAVES 6  // waves per SIMD the register allocator must leave room for: 6 = 80 VGPRs (A/B on C2: 5 → 2.62 ms, 6 → 2.48)
 #endif
 #ifndef PT_Q_WAVES_ACCEL
-#define PT_Q_WAVES_ACCEL 5  // scenes that mix BVH meshes with small ones (every other mesh scene runs pt_samples_w): 96 VGPRs, 2 spilled (6: 22 spilled)
+#define PT_Q_WAVES_ACCEL 5  // scenes that mix BVH meshes with small ones (every other mesh scene runs pt_samples_w), and scenes with a sphere BVH
+                            // next to lenses / small meshes: 96 VGPRs (at 6 waves per SIMD = 80 VGPRs these instantiations spill 21 registers)
 #endif
 #ifndef PT_Q_WAVES_SPHERE_BVH
 #define PT_Q_WAVES_SPHERE_BVH 6  // scenes whose only BVH is the sphere BVH (C4 at 8 spp, r02: 5 → 76.9 ms, 6 → 71.8 ms)
@@ -1249,7 +1250,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
                              (PT_LDS_SPHERES ? PT_LDS_SPHERE_CAP : 0);
         const bool sphere_bvh_only = sc.bvh_node_count != 0 && sc.mesh_bvh_root == nullptr;
         const bool simple_geom = sc.lens_count == 0 && sc.model_count == 0;   // spheres and planes only
-        const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : (sphere_bvh_only ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
+        const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : ((sphere_bvh_only && simple_geom) ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
         uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
         // Face records in LDS for hit_models' candidate loop: scenes whose meshes are all face-scanned (no mesh BVH) and
         // hold at most PT_LDS_FACE_CAP faces together, and only when the copy fits into what the 1 KiB allocation granule
@@ -1303,7 +1304,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
 #define PT_CALL_QUEUE(C, A)                                                                       \
     do {                                                                                          \
         if (!(A)) { if (simple_geom) PT_CALL_QUEUE_W(C, false, 0, PT_Q_WAVES); else PT_CALL_QUEUE_W(C, false, 1, PT_Q_WAVES); } \
-        else if (sphere_bvh_only) { if (simple_geom) PT_CALL_QUEUE_W(C, true, 0, PT_Q_WAVES_SPHERE_BVH); else PT_CALL_QUEUE_W(C, true, 1, PT_Q_WAVES_SPHERE_BVH); } \
+        else if (sphere_bvh_only) { if (simple_geom) PT_CALL_QUEUE_W(C, true, 0, PT_Q_WAVES_SPHERE_BVH); else PT_CALL_QUEUE_W(C, true, 1, PT_Q_WAVES_ACCEL); } \
         else PT_CALL_QUEUE_W(C, true, 2, PT_Q_WAVES_ACCEL);                                       \
     } while (0)
 #define PT_CALL_FIXED(C, A) \
