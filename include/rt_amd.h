@@ -320,10 +320,12 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
                                            take the brute-force loops: the walks address 32-bit offsets)      */
 #define RT_OPT_WALK_SLICES 5            /* 1 (default): in scenes where every mesh of every model has a BVH, the
                                            lanes' mesh walks advance in interleaved slices; 0: every walk runs in place */
-#define RT_OPT_PREFIX_TREE 7            /* 1 (default): a pixel whose first random event is a dielectric surface gets a shared
-                                           DECISION TREE — glass has only two outcomes (refract / reflect, raytracer.cl:407-435),
-                                           so both continuations are traced once per pixel and every sample only picks its
-                                           branch with its own table entry; 0: every sample traces its own way through the glass */
+#define RT_OPT_PREFIX_TREE 7            /* a pixel whose first random event is a dielectric surface gets a shared DECISION TREE —
+                                           glass has only two outcomes (refract / reflect, raytracer.cl:407-435), so both
+                                           continuations are traced once per pixel and every sample only picks its branch with
+                                           its own table entry.  1 (default): in calls of >= 24 samples per pixel (below that
+                                           the trees cost more than they share); 2: in every call; 0: never — every sample
+                                           traces its own way through the glass.  Same result bit for bit in every mode */
 #define RT_OPT_ARITH 6                  /* the ARITHMETIC POLICY of the trace kernels (csrc/pt_arith.hpp).  The reference's
                                            random numbers are table entries indexed by a hash of the ray direction
                                            (raytracer.cl:113-125): one ulp re-routes a path, so "the reference's

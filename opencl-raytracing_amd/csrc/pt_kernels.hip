@@ -179,10 +179,25 @@ __global__ __launch_bounds__(256) void pt_prefix(DeviceScene sc, FrameParams fp,
     if (valid) {
         uint32_t g = 1u << fp.group_log2;
         bool final_px = (__float_as_uint(rec.p_kind.w) & 0xFFu) == REC_FINAL;
-        if (final_px && (fp.count & (g - 1u)) == 0) {
-            V3 col = xyz(rec.out), sum = mk(0.0f, 0.0f, 0.0f);
-            for (uint32_t k = 0; k < (fp.count >> fp.group_log2); k++) sum = sum + col;
-            for (uint32_t off = g >> 1; off > 0; off >>= 1) sum = sum + sum;
+        if (final_px) {
+            // `count` samples of one colour, summed in the kernels' order: lane l of the pixel's g lanes adds its samples
+            // l, l + g, … one after the other (k or k + 1 of them: the first r = count mod g lanes have one more), then the
+            // xor butterfly (offsets g/2 … 1).  Before a butterfly step over n lanes the first r lanes hold one value (X)
+            // and the others another (Y); lane l takes T(l) + T(l + n/2), so the pattern survives with n/2 lanes:
+            // r <= n/2 → (X + Y, Y + Y, r), else (X + X, X + Y, r − n/2).  Lane 0's value after the last step is the pixel's sum.
+            // (Until round 3 only counts that are multiples of g took this shortcut; every other count sent its sky pixels
+            // through the sample kernel: 56 samples per pixel took longer than 64.)
+            const V3 col = xyz(rec.out);
+            V3 Y = mk(0.0f, 0.0f, 0.0f);
+            for (uint32_t k = 0; k < (fp.count >> fp.group_log2); k++) Y = Y + col;
+            V3 X = Y + col;
+            uint32_t r = fp.count & (g - 1u);
+            for (uint32_t n = g; n > 1u; n >>= 1) {
+                const uint32_t h = n >> 1;
+                if (r <= h) { X = X + Y; Y = Y + Y; }
+                else { Y = X + Y; X = X + X; r -= h; }
+            }
+            const V3 sum = r ? X : Y;
             accumulate(accum, (size_t)y * fp.w + x, sum, fp.count);
             if (COUNT) cn.c[CN_SAMPLES] += 1;  // scaled by count below
         } else {
@@ -435,6 +450,9 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
     }
     return p < 1u ? 1u : p;
 }
+#ifndef PT_TREE_MIN_SAMPLES
+#define PT_TREE_MIN_SAMPLES 24u   // samples per call from which the shared decision trees pay (launch_fused; RT_OPT_PREFIX_TREE 1)
+#endif
 #ifndef PT_LDS_FACE_CAP
 #define PT_LDS_FACE_CAP 64u   // faces (48 bytes each) of a scene of small meshes that may be staged in LDS (launch_fused)
 #endif
@@ -1240,7 +1258,11 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         fp.trees = ctx->d_trees;
         fp.glass = ctx->d_glass;
         fp.tree_count = live_count + LIVE_TREE_COUNTER;
-        fp.tree_cap = (ctx->prefix_tree && !ctx->count_enabled && ctx->d_trees && ctx->d_tree_work) ? (uint32_t)ctx->tree_capacity : 0u;
+        // (and not for a handful of samples per call: tracing both continuations of a pixel costs more than the few samples
+        // that would share them — C2 at 1 / 8 / 16 / 32 samples per call: 0.321 / 0.457 / 0.609 / 1.031 ms with trees,
+        // 0.243 / 0.393 / 0.582 / 1.088 without)
+        const bool tree_on = ctx->prefix_tree == 2 || (ctx->prefix_tree == 1 && count >= PT_TREE_MIN_SAMPLES);
+        fp.tree_cap = (tree_on && !ctx->count_enabled && ctx->d_trees && ctx->d_tree_work) ? (uint32_t)ctx->tree_capacity : 0u;
         // workgroup b of pt_prefix appends to segment b mod LIVE_SEGMENTS: a segment holds at most seg_cap entries
         const uint32_t prefix_blocks = (n + 255) / 256;
         fp.seg_cap = ((prefix_blocks + LIVE_SEGMENTS - 1) / LIVE_SEGMENTS) * 256u;

@@ -1265,7 +1265,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
         case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
         case RT_OPT_WALK_SLICES: ctx->walk_slices = value != 0; return RT_OK;
-        case RT_OPT_PREFIX_TREE: ctx->prefix_tree = value != 0; return RT_OK;
+        case RT_OPT_PREFIX_TREE:
+            if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_PREFIX_TREE takes 0, 1 or 2");
+            ctx->prefix_tree = value;
+            return RT_OK;
         case RT_OPT_ACCEL:
             if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_ACCEL takes 0, 1 or 2");
             ctx->accel = value;

@@ -58,6 +58,7 @@ def test_random_scene_bit_exact(seed, oracle, table):
     s, cam = random_scene(seed)
     W, H, spp = 64, 36, (64 if seed % 3 == 0 else 8)   # 64: six pixels per wave, full waves of the sample queue
     t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
+    t.setOption(t.OPT_PREFIX_TREE, 2 if seed % 2 else 1)   # odd seeds: decision trees in the 8-sample calls too (default: from 24 on)
     g = np.random.RandomState(seed + 5000)
     n = 1200
     xs, ys, ss = g.randint(0, W, n), g.randint(0, H, n), g.randint(0, 3000, n)
@@ -106,6 +107,7 @@ def test_random_scene_bit_exact_against_the_rocm_opencl_build(seed):
     ref = orc.ReferenceGfx950(_HSACO[policy])
     t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
     t.setArith(policy)
+    t.setOption(t.OPT_PREFIX_TREE, 2 if seed % 4 < 2 else 1)   # the decision trees in the one-sample calls too, for half the seeds
     t.resetCounters()
     table = t.getRandomTable()
     for k in range(3):

@@ -697,6 +697,42 @@ def test_live_list_far_shorter_than_the_grid(spp, oracle, table):
         t.close()
 
 
+def test_final_pixels_sum_in_kernel_order_at_every_count():
+    """A pixel whose path ends before any random event (sky, a light seen directly or through mirrors) is summed by
+    pt_prefix in closed form: `count` equal samples through the kernels' summation tree (g lanes adding their samples one
+    after the other, then the xor butterfly).  Against the direct path (RT_OPT_PREFIX_SHARING 0: every sample traced
+    from the camera and summed by the real butterfly) bit for bit, for counts on both sides of every lane-group size,
+    with light colours whose sums round differently in different orders."""
+    s = rt.SceneCreator()
+    s.addMaterial(rt._abi.T_LIGHT, (0.7, 0.3, 0.9), 0)          # 0
+    s.addMaterial(rt._abi.T_LIGHT, (0.1, 1.0 / 3.0, 0.57), 0)   # 1
+    s.addMaterial(rt._abi.T_REFLECTIVE, (0.9, 0.8, 0.65), 0.77) # 2: a mirror in front of the lights (a final colour after a bounce)
+    s.addMaterial(rt._abi.T_DIFFUSE, (0.5, 0.5, 0.5), 1)        # 3
+    s.addSphere((-3.0, 0.0, 8.0), 2.5, 0)
+    s.addSphere((3.0, 0.0, 8.0), 2.5, 1)
+    s.addSphere((0.0, 2.5, 5.0), 1.0, 2)
+    s.addSphere((0.0, -2.5, 5.0), 1.0, 3)
+    cam = rt.Camera(60, 2.0, (0, 0, 0), 0.0, 0.0).transferData()
+    W, H = 128, 64
+    t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
+    for arith in (0, 2):
+        t.setArith(arith)
+        for spp in (1, 2, 3, 5, 7, 8, 9, 15, 24, 31, 33, 47, 56, 63, 64, 65, 100, 127, 129, 200, 257, 500):
+            frames = []
+            for sharing in (1, 0):
+                t.setOption(t.OPT_PREFIX_SHARING, sharing)
+                t.clear()
+                t.renderSamples(cam, 3, spp)
+                t.sync()
+                frames.append(t.readLinear().copy())
+            assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (arith, spp)
+            if spp == 100:   # the frame holds all four kinds of pixel: sky, the two lights, mirror, diffuse
+                rgb = frames[0][..., :3]
+                assert (rgb.sum(axis=2) == 0).any() and len(np.unique(rgb.reshape(-1, 3), axis=0)) > 50
+    assert t.walkOverflow() == 0
+    t.close()
+
+
 def _glass_stack_scene():
     """Nested and adjacent glass: concentric dielectric shells, touching dielectric spheres, a refractive ball and a
     mirror between them, over a diffuse floor — first-hit pixels whose decision trees run out of their budget of 7
@@ -736,15 +772,22 @@ def test_decision_trees_change_no_bit(case, arith, oracle, table):
     t.resetCounters()
     for spp, first in ((1, 0), (5, 3), (64, 0), (200, 7)):
         frames = []
-        for tree in (1, 0):
+        for tree in (2, 0):    # 2: trees in every call (1, the default, leaves them out below 24 samples per call)
             t.setOption(t.OPT_PREFIX_TREE, tree)
             t.clear()
             t.renderSamples(cam, first, spp)
             t.sync()
             frames.append(t.readLinear().copy())
         assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (case, spp)
-    # the fixed-lane kernel (sample queue off) and slot ranges (several launches per frame) read the trees too
     t.setOption(t.OPT_PREFIX_TREE, 1)
+    for spp in (8, 24):    # the default mode on either side of its threshold
+        t.clear(); t.renderSamples(cam, 0, spp); t.sync()
+        auto = t.readLinear().copy()
+        t.setOption(t.OPT_PREFIX_TREE, 0)
+        t.clear(); t.renderSamples(cam, 0, spp); t.sync()
+        assert np.array_equal(auto.view(np.uint32), t.readLinear().view(np.uint32)), (case, spp)
+        t.setOption(t.OPT_PREFIX_TREE, 1)
+    # the fixed-lane kernel (sample queue off) and slot ranges (several launches per frame) read the trees too
     t.setOption(t.OPT_SAMPLE_QUEUE, 0)
     t.clear(); t.renderSamples(cam, 0, 64); t.sync()
     fixed = t.readLinear().copy()

@@ -98,6 +98,7 @@ def test_every_pixel_sample_is_bit_identical_to_the_rocm_opencl_build(name, poli
     ref = orc.ReferenceGfx950(HSACO[policy])
     t = rt.RayTracer(W, H, scene=wl.scene, seed=cases.SEED)
     t.setArith(policy)
+    t.setOption(t.OPT_PREFIX_TREE, 2)   # the decision trees in the one-sample calls below too (default: from 24 samples per call on)
     t.resetCounters()
     table = t.getRandomTable()
     lit = 0.0

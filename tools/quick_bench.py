@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-time survey over workloads and library variants (GPU box):
-    tools/quick_bench.py [--lib=PATH] [--queue=0|1] [--arith=0|1|2] [--tree=0|1] c2:64 c3:256 c4:2 c5:2[:W:H]
+    tools/quick_bench.py [--lib=PATH] [--queue=0|1] [--arith=0|1|2] [--tree=0|1|2] c2:64 c3:256 c4:2 c5:2[:W:H]
 Prints the best of 5 HIP-event times of the fused trace call and a hash of the accumulator (every
 variant of the library must print the same hash for the same spec: results never depend on tuning)."""
 import hashlib
