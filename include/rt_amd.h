@@ -274,6 +274,8 @@ int rt_sample_counter(const rt_context *ctx, uint32_t *out);
  * 4th channel, so accumulators of several ranks can simply be summed).
  * rt_clear() zeroes it; rt_resolve() writes image = sqrt(sum / count), alpha 1.
  * 64 spp: rt_clear; rt_render_spp(cam, 0, 64); rt_resolve.
+ * A call of more than 512 samples per pixel is executed as consecutive launches of 512 (the accumulator is the sum of
+ * their sums; results within a launch are summed in a fixed order).
  */
 int rt_clear(rt_context *ctx);
 int rt_render_spp(rt_context *ctx, const float camera[12], uint32_t first_sample, uint32_t n_samples);

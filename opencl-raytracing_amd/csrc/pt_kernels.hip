@@ -422,6 +422,7 @@ __host__ __device__ inline uint32_t queue_wave_lds_bytes(uint32_t pixels_per_wav
 #ifndef PT_Q_WAVES_SPHERE_BVH
 #define PT_Q_WAVES_SPHERE_BVH 6  // scenes whose only BVH is the sphere BVH (C4 at 8 spp, r02: 5 → 76.9 ms, 6 → 71.8 ms)
 #endif
+static_assert(QUEUE_SLOTS >= RT_SPP_PER_LAUNCH, "rt_render_spp's launches must fit a wave's sample queue");
 #ifndef QUEUE_MIN_SAMPLES
 #define QUEUE_MIN_SAMPLES 384u
 #endif

@@ -36,6 +36,7 @@ struct DevBuf {
 namespace pt { struct KernelSet; }
 
 #define ACCEL_MIN_SPHERES 64
+#define RT_SPP_PER_LAUNCH 512u   // samples per pixel of one trace launch (rt_render_spp splits larger calls); = QUEUE_SLOTS of pt_kernels.hip
 #ifndef MESH_BVH_MIN_FACES
 #define MESH_BVH_MIN_FACES 32
 #endif

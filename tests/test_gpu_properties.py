@@ -102,7 +102,7 @@ def test_edge_cases(oracle, table):
     got = t.traceSamples(wl.camera, xs, ys, ss)
     exp, _ = oracle.samples(wl.scene, wl.camera, table, 40, 24, xs, ys, ss)
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
-    for spp in (1, 2, 63, 65, 130, 600):                    # non-power-of-two counts; > 512 leaves the sample queue
+    for spp in (1, 2, 63, 65, 130, 600):                    # non-power-of-two counts; > 512: two launches
         img = t.renderFrame(wl.camera, spp)
         ref, _ = oracle.render(wl.scene, wl.camera, table, 40, 24, 2, count=spp, threads=8)
         assert (np.abs(img - ref) / np.maximum(np.maximum(np.abs(img), np.abs(ref)), 1e-6)).max() <= 1e-4, spp
