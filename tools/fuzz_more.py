@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_more.py <first seed> <last seed> — the random scenes of tests/test_gpu_fuzz.py at 8 / 64 / 256 / 512 samples per
+"""tools/fuzz_more.py <first seed> <last seed> [odd] — the random scenes of tests/test_gpu_fuzz.py at 8 / 64 / 256 / 512 samples per
 pixel, all three acceleration modes, three repeats each (the order of pt_prefix's appends differs from run to run), fused
 frames bit for bit against the oracle's per-sample values summed in kernel order.  Round 2: seeds 200-399, no mismatch."""
 import sys, os, time, numpy as np
@@ -14,7 +14,7 @@ bad=0; t0=time.time()
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     s,cam=random_scene(seed)
     W,H=48,27
-    spp=[8,64,256][seed%3] if seed%9 else 512
+    spp=([8,64,256][seed%3] if seed%9 else 512) if len(sys.argv) < 4 else [5,24,47,100,200,300,511][seed%7]   # any 4th argument: counts off the lane-group grid
     t=rt.RayTracer(W,H,scene=s,seed=cases.SEED)
     yy,xx,sm=np.meshgrid(np.arange(H),np.arange(W),np.arange(spp),indexing='ij')
     per,_=o.samples(s,cam,tab,W,H,xx.ravel(),yy.ravel(),sm.ravel())
