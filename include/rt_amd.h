@@ -328,6 +328,9 @@ int rt_device_accum(rt_context *ctx, void **d_rgba);
                                            its own table entry.  1 (default): in calls of >= 24 samples per pixel (below that
                                            the trees cost more than they share); 2: in every call; 0: never — every sample
                                            traces its own way through the glass.  Same result bit for bit in every mode */
+#define RT_OPT_WAVE_FILL 8              /* 1 (default): a sample-kernel wave owns fewer pixels when the launch is small (a small
+                                           frame, a rank's share of a sharded one), so that the chip's wave slots are filled;
+                                           0: always as many pixels per wave as its LDS share holds.  Same result bit for bit */
 #define RT_OPT_ARITH 6                  /* the ARITHMETIC POLICY of the trace kernels (csrc/pt_arith.hpp).  The reference's
                                            random numbers are table entries indexed by a hash of the ray direction
                                            (raytracer.cl:113-125): one ulp re-routes a path, so "the reference's

@@ -451,6 +451,9 @@ __host__ inline uint32_t queue_pixels_per_wave(uint32_t count, uint32_t waves, u
     }
     return p < 1u ? 1u : p;
 }
+#ifndef PT_UNITS_PER_WAVE_SLOT
+#define PT_UNITS_PER_WAVE_SLOT 16u   // waves a sample-kernel launch should have per wave slot of the chip (launch_fused)
+#endif
 #ifndef PT_TREE_MIN_SAMPLES
 #define PT_TREE_MIN_SAMPLES 24u   // samples per call from which the shared decision trees pay (launch_fused; RT_OPT_PREFIX_TREE 1)
 #endif
@@ -1275,6 +1278,16 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         const bool simple_geom = sc.lens_count == 0 && sc.model_count == 0;   // spheres and planes only
         const uint32_t q_waves = !scene_has_accel(sc) ? PT_Q_WAVES : ((sphere_bvh_only && simple_geom) ? PT_Q_WAVES_SPHERE_BVH : PT_Q_WAVES_ACCEL);
         uint32_t ppw = queue_pixels_per_wave(count, q_waves, static_f4, PT_Q_BLOCK_WAVES);
+        // Small launches (small frames, a rank's share of a sharded frame): fewer pixels per wave, so that there are about
+        // PT_UNITS_PER_WAVE_SLOT waves per wave slot of the chip — a wave works through its pixels' samples one batch of
+        // 64 after the other, and 4 200 waves of 384 samples leave a third of the slots empty for the whole launch.
+        // C2 at 64 spp, 6 pixels per wave vs this rule: 200 x 126 0.314 → 0.140 ms, 320 x 180 0.336 → 0.187, 480 x 270
+        // 0.344 → 0.268, 640 x 360 0.419 → 0.369, 960 x 540 0.619 → 0.59; 1080p and up unchanged (6).
+        const uint32_t want_units = (uint32_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 4u * 6u * PT_UNITS_PER_WAVE_SLOT;
+        // (never fewer than the 64 samples that fill a wave's lanes once)
+        const uint32_t ppw_full = (64u + count - 1u) / count;
+        const uint32_t ppw_par = !ctx->wave_fill ? QUEUE_MAX_PIXELS : std::max(n / want_units, ppw_full);
+        if (ppw > ppw_par) ppw = ppw_par;
         // Face records in LDS for hit_models' candidate loop: scenes whose meshes are all face-scanned (no mesh BVH) and
         // hold at most PT_LDS_FACE_CAP faces together, and only when the copy fits into what the 1 KiB allocation granule
         // leaves over anyway (C3: 576 bytes of a cube into 609 spare ones) — never at the price of a pixel per wave.
@@ -1282,7 +1295,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
         if (PT_FACE_MASK && !simple_geom && sc.mesh_bvh_root == nullptr && !ctx->count_enabled) {
             const size_t nf = ctx->h_faces.size() / 3u - (ctx->h_faces.empty() ? 0u : 1u);   // (the array ends with one dummy record)
             if (nf > 0 && nf <= PT_LDS_FACE_CAP &&
-                queue_pixels_per_wave(count, q_waves, static_f4 + 3u * (uint32_t)nf, PT_Q_BLOCK_WAVES) == ppw) {
+                queue_pixels_per_wave(count, q_waves, static_f4 + 3u * (uint32_t)nf, PT_Q_BLOCK_WAVES) >= ppw) {
                 fp.lds_face_f4 = 3u * (uint32_t)nf;
                 static_f4 += fp.lds_face_f4;
             }
@@ -1335,6 +1348,7 @@ int launch_fused(rt_context *ctx, const float cam[12], uint32_t first, uint32_t 
             if (queue && sc.mesh_bvh_root && ctx->walk_jobs.n && ctx->walk_slices && !ctx->count_enabled && !PT_LDS_SPHERES) {
                 // every mesh has a BVH: interleaved walk slices (pt_samples_w), sized for its own occupancy target
                 uint32_t ppw_w = queue_pixels_per_wave(count, ctx->walk_jobs.n == 1 ? PT_W_WAVES : PT_W_WAVES_MULTI, static_f4, PT_W_BLOCK_WAVES);
+                if (ppw_w > ppw_par) ppw_w = ppw_par;
                 size_t lds_w = static_f4 * sizeof(float4) + PT_W_BLOCK_WAVES * (size_t)queue_wave_lds_bytes(ppw_w, count);
                 dim3 gridw((units(ppw_w) + PT_W_BLOCK_WAVES - 1) / PT_W_BLOCK_WAVES), blockw(64 * PT_W_BLOCK_WAVES);
                 if (ctx->walk_jobs.n == 1)

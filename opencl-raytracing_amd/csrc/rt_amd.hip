@@ -1272,6 +1272,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
         case RT_OPT_PREFIX_SHARING: ctx->prefix_sharing = value != 0; return RT_OK;
         case RT_OPT_SAMPLE_QUEUE: ctx->sample_queue = value != 0; return RT_OK;
         case RT_OPT_WALK_SLICES: ctx->walk_slices = value != 0; return RT_OK;
+        case RT_OPT_WAVE_FILL: ctx->wave_fill = value != 0; return RT_OK;
         case RT_OPT_PREFIX_TREE:
             if (value < 0 || value > 2) return fail(ctx, RT_EINVAL, "RT_OPT_PREFIX_TREE takes 0, 1 or 2");
             ctx->prefix_tree = value;

@@ -101,6 +101,7 @@ struct rt_context {
     uint32_t *d_glass = nullptr;        // live-list positions of those pixels (pt_prefix → pt_tree_pass)
     pt::TreeWork *d_tree_work = nullptr;  // glass vertices waiting for the next level: two queues of tree_capacity entries
     size_t tree_capacity = 0;
+    bool wave_fill = true;              // RT_OPT_WAVE_FILL
     int prefix_tree = 1;                // RT_OPT_PREFIX_TREE: 0 off, 1 from PT_TREE_MIN_SAMPLES samples per call on, 2 always
     bool prefix_sharing = true;
     bool sample_queue = true;

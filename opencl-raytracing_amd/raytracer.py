@@ -31,7 +31,7 @@ SYMBOLS = (
 )
 
 # rt_set_option: options and the arithmetic policies of RT_OPT_ARITH (include/rt_amd.h)
-OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH, OPT_PREFIX_TREE = 1, 2, 3, 4, 5, 6, 7
+OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH, OPT_PREFIX_TREE, OPT_WAVE_FILL = 1, 2, 3, 4, 5, 6, 7, 8
 ARITH_IEEE, ARITH_ROCM_OCL_NOCONTRACT, ARITH_ROCM_OCL = 0, 1, 2
 ARITH_NAMES = {"ieee": ARITH_IEEE, "rocm-opencl-nocontract": ARITH_ROCM_OCL_NOCONTRACT, "rocm-opencl": ARITH_ROCM_OCL}
 
@@ -227,7 +227,7 @@ class RayTracer:
     def setShard(self, rank, world, tile_w=8, tile_h=8):
         self._check(self._lib.rt_set_shard(self._ctx, rank, world, tile_w, tile_h))
 
-    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH, OPT_PREFIX_TREE = 1, 2, 3, 4, 5, 6, 7
+    OPT_PREFIX_SHARING, OPT_MAX_THREADS_PER_LAUNCH, OPT_SAMPLE_QUEUE, OPT_ACCEL, OPT_WALK_SLICES, OPT_ARITH, OPT_PREFIX_TREE, OPT_WAVE_FILL = 1, 2, 3, 4, 5, 6, 7, 8
 
     def setOption(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, option, int(value)))

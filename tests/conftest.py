@@ -53,3 +53,26 @@ def _no_walk_ever_ends_on_its_loop_bound():
     rt.RayTracer.close = close
     yield
     rt.RayTracer.close = orig
+
+
+@pytest.fixture(autouse=True)
+def _both_wave_fill_modes(request):
+    """The test frames are small, and on a small launch a sample-kernel wave owns fewer pixels (RT_OPT_WAVE_FILL 1, the
+    default).  So that the regime of the full-size frames — as many pixels per wave as its LDS share holds — stays
+    covered, every other test (by its name) creates its RayTracers with RT_OPT_WAVE_FILL 0.  Results never depend on it."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import zlib
+    import cases
+    rt = cases.rt
+    fill = zlib.crc32(request.node.nodeid.encode()) & 1
+    orig = rt.RayTracer.__init__
+
+    def init(self, *a, **kw):
+        orig(self, *a, **kw)
+        self.setOption(self.OPT_WAVE_FILL, fill)
+
+    rt.RayTracer.__init__ = init
+    yield
+    rt.RayTracer.__init__ = orig

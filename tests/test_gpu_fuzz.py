@@ -59,6 +59,7 @@ def test_random_scene_bit_exact(seed, oracle, table):
     W, H, spp = 64, 36, (64 if seed % 3 == 0 else 8)   # 64: six pixels per wave, full waves of the sample queue
     t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
     t.setOption(t.OPT_PREFIX_TREE, 2 if seed % 2 else 1)   # odd seeds: decision trees in the 8-sample calls too (default: from 24 on)
+    t.setOption(t.OPT_WAVE_FILL, 0 if seed % 3 == 1 else 1)  # a third of the seeds: as many pixels per wave as the LDS share holds
     g = np.random.RandomState(seed + 5000)
     n = 1200
     xs, ys, ss = g.randint(0, W, n), g.randint(0, H, n), g.randint(0, 3000, n)
@@ -108,6 +109,7 @@ def test_random_scene_bit_exact_against_the_rocm_opencl_build(seed):
     t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
     t.setArith(policy)
     t.setOption(t.OPT_PREFIX_TREE, 2 if seed % 4 < 2 else 1)   # the decision trees in the one-sample calls too, for half the seeds
+    t.setOption(t.OPT_WAVE_FILL, 0 if seed % 3 == 1 else 1)
     t.resetCounters()
     table = t.getRandomTable()
     for k in range(3):

@@ -173,6 +173,17 @@ def test_prefix_sharing_and_sample_queue_change_no_bit(name, kw, spps):
         for o in out[1:]:
             assert np.array_equal(out[0][0].view(np.uint32), o[0].view(np.uint32)), spp
             assert out[0][1] == o[1], spp
+        # pixels per wave: adapted to the (small) launch by default; as many as the LDS share holds with RT_OPT_WAVE_FILL 0,
+        # with the decision trees on either way
+        t.setOption(t.OPT_PREFIX_SHARING, 1)
+        t.setOption(t.OPT_SAMPLE_QUEUE, 1)
+        for fill in (0, 1):
+            t.setOption(t.OPT_WAVE_FILL, fill)
+            t.setOption(t.OPT_PREFIX_TREE, 2)
+            t.clear()
+            t.renderSamples(wl.camera, 5, spp)
+            assert np.array_equal(out[0][0].view(np.uint32), t.readLinear().view(np.uint32)), (spp, fill)
+        t.setOption(t.OPT_PREFIX_TREE, 1)
     t.close()
 
 

@@ -16,6 +16,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     W,H=48,27
     spp=([8,64,256][seed%3] if seed%9 else 512) if len(sys.argv) < 4 else [5,24,47,100,200,300,511][seed%7]   # any 4th argument: counts off the lane-group grid
     t=rt.RayTracer(W,H,scene=s,seed=cases.SEED)
+    t.setOption(t.OPT_WAVE_FILL, seed%2)   # even seeds: as many pixels per wave as the LDS share holds (the frames are tiny)
     yy,xx,sm=np.meshgrid(np.arange(H),np.arange(W),np.arange(spp),indexing='ij')
     per,_=o.samples(s,cam,tab,W,H,xx.ravel(),yy.ravel(),sm.ravel())
     exp=(fused_sum_in_kernel_order(per.reshape(H*W,spp,3),spp).reshape(H,W,3)/np.float32(spp)).astype(np.float32)

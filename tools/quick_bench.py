@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-time survey over workloads and library variants (GPU box):
-    tools/quick_bench.py [--lib=PATH] [--queue=0|1] [--arith=0|1|2] [--tree=0|1|2] c2:64 c3:256 c4:2 c5:2[:W:H]
+    tools/quick_bench.py [--lib=PATH] [--queue=0|1] [--arith=0|1|2] [--tree=0|1|2] [--fill=0|1] c2:64 c3:256 c4:2 c5:2[:W:H]
 Prints the best of 5 HIP-event times of the fused trace call and a hash of the accumulator (every
 variant of the library must print the same hash for the same spec: results never depend on tuning)."""
 import hashlib
@@ -18,11 +18,13 @@ if args and args[0].startswith("--lib="):
 queue = None
 if args and args[0].startswith("--queue="):
     queue = int(args.pop(0)[8:])
-arith, tree = 2, None
-while args and args[0].startswith(("--arith=", "--tree=")):
+arith, tree, fill = 2, None, None
+while args and args[0].startswith(("--arith=", "--tree=", "--fill=")):
     k, v = args.pop(0).split("=")
     if k == "--arith":
         arith = int(v)
+    elif k == "--fill":
+        fill = int(v)
     else:
         tree = int(v)
 for spec in args:
@@ -38,6 +40,8 @@ for spec in args:
     t.setArith(arith)
     if tree is not None:
         t.setOption(t.OPT_PREFIX_TREE, tree)
+    if fill is not None:
+        t.setOption(t.OPT_WAVE_FILL, fill)
     t.clear(); t.renderSamples(wl.camera, 0, spp); t.sync()
     digest = hashlib.sha1(t.readLinear().tobytes()).hexdigest()[:12]
     ms = []
