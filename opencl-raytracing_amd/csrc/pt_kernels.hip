@@ -825,6 +825,20 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
     uint32_t nb_face = 0, nb_mat = 0;
     float nb_u = 0.0f, nb_v = 0.0f;
 
+    // MULTI: move `job` on to the next mesh whose ROOT the ray does not miss — the root's node test runs here, in the cheap
+    // code, so a bounce costs a walk slice per mesh the ray may touch, not one per mesh of the scene — and set the walk
+    // up behind that root; false: no such mesh is left (the bounce's mesh search is over)
+    auto enter_job = [&]() {
+        while (job < n_jobs) {
+            const uint32_t mesh_n = jobs[job].x;
+            wbest = sc.meshes[mesh_n].face_count;
+            wt = wu = wv = 0.0f;
+            wpos = mesh_walk_first(sc, r, sc.mesh_bvh_root[mesh_n], wbest);
+            if (wpos.cur != PT_MESH_END) return true;
+            job++;
+        }
+        return false;
+    };
 #ifdef PT_WSTAT
     WalkStat ws = {0, 0, 0, 0, 0};
     unsigned long long it_n = 0, it_active = 0, it_p0 = 0, it_p1 = 0, it_p2 = 0, it_walk_calls = 0;
@@ -977,12 +991,14 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                     if (!MULTI) {
                         wpos = mesh_walk_first(sc, r, root0, faces0);
                         if (wpos.cur == PT_MESH_END) phase = 2;
+                    } else if (!enter_job()) {
+                        phase = 2;
                     }
 #endif
                 }
             }
 #if PT_W_ROOT_FIRST
-            if (MULTI || again >= PT_W_CHEAP_REPEATS) break;
+            if (again >= PT_W_CHEAP_REPEATS) break;
             if ((uint32_t)__popcll(__ballot((active && phase != 1) || (!active && next < total))) < PT_W_CHEAP_AGAIN) break;
 #else
             break;
@@ -1017,6 +1033,9 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                     nb_v = wv;
                 }
                 job++;
+#if PT_W_ROOT_FIRST
+                if (!enter_job()) phase = 2;   // (the next mesh whose root the ray does not miss: stay in state 1)
+#else
                 if (MULTI && job < n_jobs) {  // next mesh: stay in state 1
                     uint32_t mesh_n = jobs[job].x;
                     wpos = mesh_walk_start(sc.mesh_bvh_root[mesh_n]);
@@ -1025,6 +1044,7 @@ __global__ __launch_bounds__(64 * PT_W_BLOCK_WAVES, MULTI ? PT_W_WAVES_MULTI : P
                 } else {
                     phase = 2;
                 }
+#endif
                 }
             }
         }
