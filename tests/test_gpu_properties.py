@@ -728,7 +728,7 @@ def test_final_pixels_sum_in_kernel_order_at_every_count():
     t = rt.RayTracer(W, H, scene=s, seed=cases.SEED)
     for arith in (0, 2):
         t.setArith(arith)
-        for spp in (1, 2, 3, 5, 7, 8, 9, 15, 24, 31, 33, 47, 56, 63, 64, 65, 100, 127, 129, 200, 257, 500):
+        for spp in (1, 2, 3, 5, 7, 8, 9, 15, 24, 31, 33, 47, 56, 63, 64, 65, 100, 127, 129, 200, 257, 500, 512, 513, 600, 1100):   # > 512: launches of 512
             frames = []
             for sharing in (1, 0):
                 t.setOption(t.OPT_PREFIX_SHARING, sharing)
