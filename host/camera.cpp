@@ -27,6 +27,9 @@ void Camera::updateVectors() {
 void Camera::setFov() {
     // the reference approximates 1/180 by 0.0055556f here (src/camera.cpp:40) ...
     float angle = (float)(fov * M_PI * 0.0055556f);
+    // The reference calls an UNQUALIFIED tan on a float (src/camera.cpp:41,48): the float overload where the platform's
+    // headers put one in the global namespace (libc++, the author's platform), otherwise ::tan(double) rounded to float —
+    // the two can differ in the last bit.  Here, and in camera.py: the float function (tanf).  Unpinned, like every libm call.
     half_height = std::tan(angle * 0.5f);
     half_width = aspect * half_height;
     updateVectors();
