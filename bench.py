@@ -373,7 +373,9 @@ def main():
     base_spp = args.spp or wl.spp
     wl.spp = base_spp
     spp = base_spp * world if scaling == "weak" else base_spp
-    chunk = spp if spp <= 512 else base_spp          # samples per fused call: ONE call per step (a wave's queue holds up to 512 samples)
+    # samples per fused call: ONE call per step up to 512 samples per pixel (the capacity of a wave's sample queue); beyond
+    # that calls of 512 when that divides the count (the library itself would split a larger call the same way)
+    chunk = spp if spp <= 512 else (512 if spp % 512 == 0 else base_spp)
     key = profile_key(workload, wl.width, wl.height, base_spp)
     tracer = rt.RayTracer(wl.width, wl.height, scene=wl.scene, device=device, seed=rt.workloads.SEED)
     tracer.setArith(args.arith)
